@@ -1,0 +1,169 @@
+/*
+ * tinyrt.h — C ABI of the MI355X-native path-tracing sampler (libtinyrt.so).
+ *
+ * Drop-in boundary for ONE path of cheolwanpark/tiny-raytracer: the per-pixel Monte-Carlo
+ * bounce loop (`CpuSampler::single_point_sampling`, raytracer/src/renderer/sampler/cpu.rs:39-65)
+ * together with the primary-ray generation that feeds it (renderer/pointgen.rs:37-52,
+ * camera.rs:58-66) and the f32 accumulation that drains it (renderer/imager.rs:34-60).
+ *
+ * The reference's plug-in point is `trait Sampler::sampling(world, Receiver<SamplePoint>,
+ * Sender<SampledColor>)` (renderer/sampler/mod.rs:10-17), invoked by `Renderer::render`
+ * (renderer/renderer.rs:45-49,68-70).  One 32-byte message in and one 20-byte message out
+ * per sample cannot feed a GPU, so the boundary sits one level up, at the
+ * World / Camera / Renderer::render() surface; `trt_sample_batch` keeps the literal
+ * batch form (SamplePoint[] -> SampledColor[]) the reference's own GPU sampler uses
+ * (renderer/sampler/metal/sampler.rs:49-65,107-130).
+ *
+ * Conventions: plain C, POD only, no exceptions cross this boundary.  Every function that
+ * can fail returns `int`: 0 = TRT_OK, negative = error; `trt_last_error()` gives the
+ * message of the calling thread's last failure.  (The reference panics instead:
+ * cpu.rs:35,85; world.rs:29-31; renderer.rs:75-77.)  Handles are opaque and owned by the
+ * library; every buffer is caller-allocated and caller-owned; the library keeps no caller
+ * pointer after a call returns.  All arithmetic is f32 (`pub type Float = f32`, lib.rs:4).
+ */
+#ifndef TINYRT_H
+#define TINYRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRT_ABI_VERSION 1
+
+enum trt_status {
+    TRT_OK = 0,
+    TRT_ERR_INVALID_ARG = -1,     /* null pointer, bad index, empty world, bad range */
+    TRT_ERR_DUPLICATE = -2,       /* material name already present (world.rs:29-31 panics) */
+    TRT_ERR_NOT_FOUND = -3,       /* material name absent (world.rs:35-41 returns None) */
+    TRT_ERR_HIP = -4,             /* HIP runtime error; message carries hipGetErrorString */
+    TRT_ERR_NO_DEVICE = -5,       /* no gfx950 device visible: the product never falls back to a CPU path */
+    TRT_ERR_OOM = -6
+};
+
+/* ---- POD layouts fixed by the reference (#[repr(C)], tightly packed, 4-byte aligned) ---- */
+typedef struct { float x, y, z; } trt_vec3;                          /* math/vec3.rs:9-15      12 B */
+typedef struct { trt_vec3 origin, direction; } trt_ray;              /* ray.rs:4-9             24 B */
+typedef struct { uint32_t x, y; trt_ray ray; } trt_sample_point;     /* renderer/pointgen.rs:7-13  32 B */
+typedef struct { uint32_t x, y; trt_vec3 color; } trt_sampled_color; /* renderer/imager.rs:9-15    20 B */
+
+/* ---- materials (material/{lambertian,metal,dielectric,light}.rs) ---- */
+enum trt_material_kind {
+    TRT_LAMBERTIAN = 0,   /* Lambertian::new(albedo)                  lambertian.rs:10-12 */
+    TRT_METAL = 1,        /* Metal::new(albedo, fuzz), fuzz clamped   metal.rs:12-14      */
+    TRT_DIELECTRIC = 2,   /* Dielectric::new(albedo, refraction_index) dielectric.rs:12-14 */
+    TRT_LIGHT = 3         /* Light::new(color)                        light.rs:11-13      */
+};
+typedef struct {
+    uint32_t kind;        /* enum trt_material_kind */
+    trt_vec3 albedo;      /* albedo, or emitted colour for TRT_LIGHT */
+    float param;          /* fuzz (metal) | refraction index (dielectric) | unused */
+} trt_material;
+
+/* ---- World: the scene container (hittable/world.rs:10-45) ---- */
+typedef struct trt_world trt_world;
+int trt_world_create(trt_world **out);                                            /* World::new        world.rs:16-21 */
+void trt_world_destroy(trt_world *w);
+int trt_world_add_material(trt_world *w, const char *name, const trt_material *m); /* World::add_material world.rs:27-33 */
+int trt_world_get_material(const trt_world *w, const char *name, uint32_t *index); /* World::get_material world.rs:35-41 */
+/* World::add_geometry(Box::new(Sphere::new(center, radius, material)))  world.rs:23-25, sphere.rs:16-26 */
+int trt_world_add_sphere(trt_world *w, trt_vec3 center, float radius, uint32_t material);
+/* World::add_geometry(Box::new(Quad::new(corner, u, v, material)))      world.rs:23-25, quad.rs:20-29 */
+int trt_world_add_quad(trt_world *w, trt_vec3 corner, trt_vec3 u, trt_vec3 v, uint32_t material);
+int trt_world_num_geometries(const trt_world *w);
+int trt_world_num_materials(const trt_world *w);
+
+/* ---- Scene: World::get_bvh() (world.rs:43-45 -> bvh.rs:12-22,42-84), flattened for the GPU ----
+ * Host-only work (BVH build in the reference's median-split order, threading into a
+ * pre-order skip-link array, packing into 16-byte planes).  Device upload happens lazily
+ * on first render, so a scene can be compiled and inspected on a machine without a GPU. */
+typedef struct trt_scene trt_scene;
+int trt_scene_create(const trt_world *w, trt_scene **out);
+void trt_scene_destroy(trt_scene *s);
+
+typedef struct {
+    uint32_t num_nodes, num_spheres, num_quads, num_materials;
+    uint32_t max_depth;           /* BVH depth (root = 1) */
+    uint32_t device_bytes;        /* size of the packed scene in HBM */
+    uint32_t lds_bytes;           /* bytes the megakernel stages into LDS (0 = traverses from global memory) */
+} trt_scene_info;
+int trt_scene_get_info(const trt_scene *s, trt_scene_info *out);
+/* Pre-order node dump for tests: bbox6[6*i..] = min.xyz,max.xyz; prim[i] = geometry insertion index
+ * or -1 for an inner node; skip[i] = pre-order index of the next node once subtree i is done. */
+int trt_scene_get_nodes(const trt_scene *s, float *bbox6, int32_t *prim, int32_t *skip, uint32_t cap);
+
+/* ---- Camera (camera.rs:4-14, 17-56) ---- */
+typedef struct {
+    trt_vec3 position, viewport_upper_left, forward, horizontal, vertical;
+    trt_vec3 defocus_disk_u, defocus_disk_v;
+    uint32_t width, height;
+} trt_camera;
+/* Camera::new(focus_distance, defocus_angle[deg], position, look_at, up, vertical_fov[deg], width, height) */
+int trt_camera_init(trt_camera *out, float focus_distance, float defocus_angle_deg, trt_vec3 position,
+                    trt_vec3 look_at, trt_vec3 up, float vertical_fov_deg, uint32_t width, uint32_t height);
+
+/* ---- Renderer (renderer/renderer.rs:12-35) ---- */
+enum trt_backend {
+    TRT_BACKEND_MEGAKERNEL = 0,   /* one persistent lane per pixel, whole bounce loop in one kernel */
+    TRT_BACKEND_WAVEFRONT = 1     /* ray queues in HBM: generate / extend / shade-by-material / compact */
+};
+typedef struct {
+    uint32_t samples_per_pixel;   /* Renderer::samples_per_pixel: fixes the 1/spp scale (imager.rs:35) */
+    uint32_t max_bounces;         /* Renderer::max_bounces */
+    trt_vec3 background;          /* Renderer::background_color (None -> 0, renderer.rs:33) */
+    uint32_t seed;                /* trt-rng v1 seed (the reference has no seed API: utils/random.rs:15-18) */
+    uint32_t backend;             /* enum trt_backend */
+    /* progressive / sharded rendering; zero-initialised = whole image, all samples */
+    uint32_t sample_begin, sample_end;   /* render samples [begin,end) of 0..spp; end==0 means spp */
+    uint32_t accumulate;                 /* 0: pixels start at 0; 1: continue the running sums in the buffer */
+    /* image rows owned by this call: local row r (0..rows_local) is image row
+     *   ((r / band_rows) * band_stride + band_offset) * band_rows + r % band_rows.
+     * band_rows==0 means the identity map over all `height` rows. */
+    uint32_t band_rows, band_stride, band_offset, rows_local;
+    uint32_t collect_stats;       /* 1: also count node/primitive tests (slower kernel variant) */
+} trt_render_params;
+
+typedef struct {
+    uint64_t samples;             /* single_point_sampling calls */
+    uint64_t rays;                /* closest-hit queries = world.hit calls (cpu.rs:48): the Mray/s unit */
+    uint64_t node_tests;          /* AABB slab tests (bvh.rs:89); 0 unless collect_stats */
+    uint64_t sphere_tests;        /* 0 unless collect_stats */
+    uint64_t quad_plane_tests;    /* 0 unless collect_stats */
+    uint64_t quad_inside_tests;   /* 0 unless collect_stats */
+    uint64_t shades;              /* hits whose material was evaluated; 0 unless collect_stats */
+    double kernel_ms;             /* device time of the launch(es), HIP events on the launch stream (host-buffer calls only) */
+} trt_stats;
+
+/* Renderer::render(camera, world) (renderer.rs:37-79), synchronous.  `accum` is a HOST buffer
+ * of rows*width*3 f32 linear running sums (Imager's `pixels`, imager.rs:43,50), rows =
+ * rows_local or height.  Gamma/quantisation is not applied: see trt_tonemap_u8. */
+int trt_render(trt_scene *s, const trt_camera *cam, const trt_render_params *p, float *accum, trt_stats *stats);
+
+/* Same, on buffers already resident in HBM.  `d_accum`: device pointer, rows*width*3 f32.
+ * `d_counters`: device pointer to 8 uint64 (zeroed by the caller; layout = trt_stats' first seven
+ * fields) or NULL.  `stream`: a hipStream_t (NULL = default stream).  Asynchronous: returns after
+ * enqueueing; the caller synchronises the stream. */
+int trt_render_device(trt_scene *s, const trt_camera *cam, const trt_render_params *p, float *d_accum,
+                      uint64_t *d_counters, void *stream);
+
+/* The literal Sampler plug-in form (sampler/mod.rs:10-17): n SamplePoints in, n SampledColors
+ * out, HOST buffers.  Point i uses RNG stream (seed, pixel=i, sample=0). */
+int trt_sample_batch(trt_scene *s, const trt_sample_point *in, uint32_t n, trt_sampled_color *out,
+                     uint32_t max_bounces, trt_vec3 background, uint32_t seed, trt_stats *stats);
+
+/* Imager finalisation + Image -> RgbImage (imager.rs:52-53; utils/image.rs:92-111): c^(1/gamma),
+ * clamp to [0, 0.999], *255, truncate; NaN -> 0.  HOST buffers, npixels*3 each. */
+int trt_tonemap_u8(const float *accum, uint32_t npixels, float gamma, uint8_t *rgb);
+
+/* ---- library ---- */
+const char *trt_last_error(void);
+int trt_device_count(void);               /* gfx950 devices visible; 0 without a GPU (never an error) */
+int trt_set_device(int ordinal);          /* device used by this thread's later calls */
+uint32_t trt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TINYRT_H */

@@ -1,0 +1,388 @@
+// capi.hip — the extern "C" boundary declared in include/tinyrt.h.
+//
+// Mirrors the reference's World / Camera / Renderer::render() surface (hittable/world.rs:16-45,
+// camera.rs:17-56, renderer/renderer.rs:21-79) as opaque handles + POD structs.  The reference
+// panics on misuse; here every failure is a negative status plus a thread-local message, and no
+// C++ exception leaves this file.  There is no CPU fallback: without a gfx950 device every
+// compute entry point fails with TRT_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <new>
+#include <string>
+#include <unordered_map>
+
+#include "kernels.h"
+#include "scene.h"
+
+using namespace trt;
+
+struct trt_world {
+    World w;
+};
+
+struct trt_scene {
+    SceneHost host;
+    std::mutex mu;
+    std::unordered_map<int, float4*> device_blob;     // device ordinal -> packed scene in HBM
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+    return fail(TRT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define TRT_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return fail_hip(e_, #call);    \
+    } while (0)
+
+int require_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(TRT_ERR_NO_DEVICE, "no HIP device visible: libtinyrt has no CPU path, it needs a gfx950 GPU");
+    }
+    return TRT_OK;
+}
+
+// Uploads the packed scene to the current device on first use.
+int scene_on_device(trt_scene* s, SceneDev& out) {
+    int dev = 0;
+    TRT_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(s->mu);
+    auto it = s->device_blob.find(dev);
+    float4* d = nullptr;
+    if (it == s->device_blob.end()) {
+        TRT_HIP(hipMalloc(reinterpret_cast<void**>(&d), s->host.layout.blob_bytes));
+        hipError_t e = hipMemcpy(d, s->host.blob.data(), s->host.layout.blob_bytes, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return fail_hip(e, "hipMemcpy(scene)"); }
+        s->device_blob.emplace(dev, d);
+    } else {
+        d = it->second;
+    }
+    out.blob = d;
+    out.L = s->host.layout;
+    return TRT_OK;
+}
+
+void to_camera_dev(const trt_camera& c, CameraDev& d) {
+    const trt_vec3* src[6] = {&c.position, &c.viewport_upper_left, &c.horizontal, &c.vertical, &c.defocus_disk_u, &c.defocus_disk_v};
+    float* dst[6] = {d.pos, d.upper_left, d.horizontal, d.vertical, d.du, d.dv};
+    for (int i = 0; i < 6; i++) { dst[i][0] = src[i]->x; dst[i][1] = src[i]->y; dst[i][2] = src[i]->z; }
+    d.width = c.width;
+    d.height = c.height;
+}
+
+// Validates params against the camera and fills the kernel arguments.  rows = rows the call owns.
+int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs& ra, uint32_t& rows) {
+    if (cam->width < 2 || cam->height < 2) return fail(TRT_ERR_INVALID_ARG, "camera width and height must be at least 2 (pointgen.rs:41-42 divides by width-1, height-1)");
+    if (p->samples_per_pixel == 0) return fail(TRT_ERR_INVALID_ARG, "samples_per_pixel must be positive");
+    uint32_t s1 = p->sample_end == 0 ? p->samples_per_pixel : p->sample_end;
+    if (p->sample_begin > s1 || s1 > p->samples_per_pixel) return fail(TRT_ERR_INVALID_ARG, "sample range must satisfy begin <= end <= samples_per_pixel");
+    if (p->backend != TRT_BACKEND_MEGAKERNEL && p->backend != TRT_BACKEND_WAVEFRONT) return fail(TRT_ERR_INVALID_ARG, "unknown backend");
+    ra.background[0] = p->background.x; ra.background[1] = p->background.y; ra.background[2] = p->background.z;
+    ra.inv_spp = 1.0f / (float)p->samples_per_pixel;
+    ra.max_bounces = p->max_bounces;
+    ra.seed_key = rng_seed_key(p->seed);
+    ra.sample_begin = p->sample_begin;
+    ra.sample_end = s1;
+    ra.accumulate = p->accumulate ? 1u : 0u;
+    if (p->band_rows == 0) {
+        ra.band_rows = 0; ra.band_stride = 1; ra.band_offset = 0;
+        rows = cam->height;
+    } else {
+        if (p->band_stride == 0 || p->band_offset >= p->band_stride) return fail(TRT_ERR_INVALID_ARG, "band_offset must be below band_stride");
+        rows = p->rows_local;
+        if (rows > 0) {
+            uint32_t last = rows - 1;
+            uint64_t y = ((uint64_t)(last / p->band_rows) * p->band_stride + p->band_offset) * p->band_rows + last % p->band_rows;
+            if (y >= cam->height) return fail(TRT_ERR_INVALID_ARG, "rows_local maps past the last image row");
+        }
+        ra.band_rows = p->band_rows; ra.band_stride = p->band_stride; ra.band_offset = p->band_offset;
+    }
+    ra.rows_local = rows;
+    return TRT_OK;
+}
+
+int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params* p, float* d_accum, uint64_t* d_counters,
+                   hipStream_t stream, uint32_t* rows_out) {
+    RenderArgs ra;
+    uint32_t rows = 0;
+    int rc = to_render_args(cam, p, ra, rows);
+    if (rc != TRT_OK) return rc;
+    if (rows_out) *rows_out = rows;
+    SceneDev sc;
+    rc = scene_on_device(s, sc);
+    if (rc != TRT_OK) return rc;
+    CameraDev cd;
+    to_camera_dev(*cam, cd);
+    const size_t bytes = (size_t)rows * cam->width * 3 * sizeof(float);
+    if (rows == 0 || ra.sample_begin == ra.sample_end || ra.max_bounces == 0) {
+        // nothing to trace: a path with no bounce budget returns colour 0 (cpu.rs:43-47,64)
+        if (!ra.accumulate && bytes) TRT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
+        return TRT_OK;
+    }
+    if (p->backend == TRT_BACKEND_WAVEFRONT) return fail(TRT_ERR_INVALID_ARG, "wavefront backend is not built into this library version");
+    TRT_HIP(launch_megakernel(sc, cd, ra, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));
+    return TRT_OK;
+}
+
+void counters_to_stats(const unsigned long long* c, trt_stats* st) {
+    st->samples = c[CTR_SAMPLES]; st->rays = c[CTR_RAYS]; st->node_tests = c[CTR_NODE]; st->sphere_tests = c[CTR_SPHERE];
+    st->quad_plane_tests = c[CTR_QUAD_PLANE]; st->quad_inside_tests = c[CTR_QUAD_INSIDE]; st->shades = c[CTR_SHADE];
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t trt_abi_version(void) { return TRT_ABI_VERSION; }
+const char* trt_last_error(void) { return g_last_error.c_str(); }
+
+int trt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+int trt_set_device(int ordinal) {
+    int rc = require_device();
+    if (rc != TRT_OK) return rc;
+    TRT_HIP(hipSetDevice(ordinal));
+    return TRT_OK;
+}
+
+// ---- World ----
+int trt_world_create(trt_world** out) {
+    if (!out) return fail(TRT_ERR_INVALID_ARG, "out is null");
+    trt_world* w = new (std::nothrow) trt_world();
+    if (!w) return fail(TRT_ERR_OOM, "out of memory");
+    *out = w;
+    return TRT_OK;
+}
+void trt_world_destroy(trt_world* w) { delete w; }
+
+int trt_world_add_material(trt_world* w, const char* name, const trt_material* m) {
+    if (!w || !name || !m) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    if (m->kind > TRT_LIGHT) return fail(TRT_ERR_INVALID_ARG, "unknown material kind");
+    try {
+        std::string key(name);
+        if (w->w.material_index.count(key)) return fail(TRT_ERR_DUPLICATE, key + " key is already in the material table");   // world.rs:30
+        trt_material mm = *m;
+        if (mm.kind == TRT_METAL) mm.param = fminf(fmaxf(mm.param, 0.0f), 1.0f);      // Metal::new clamps fuzz (metal.rs:12-14)
+        w->w.material_index.emplace(key, (uint32_t)w->w.materials.size());
+        w->w.materials.push_back(mm);
+    } catch (const std::bad_alloc&) {
+        return fail(TRT_ERR_OOM, "out of memory");
+    }
+    return TRT_OK;
+}
+int trt_world_get_material(const trt_world* w, const char* name, uint32_t* index) {
+    if (!w || !name || !index) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    auto it = w->w.material_index.find(name);
+    if (it == w->w.material_index.end()) return fail(TRT_ERR_NOT_FOUND, std::string("no material named ") + name);
+    *index = it->second;
+    return TRT_OK;
+}
+int trt_world_add_sphere(trt_world* w, trt_vec3 center, float radius, uint32_t material) {
+    if (!w) return fail(TRT_ERR_INVALID_ARG, "world is null");
+    if (material >= w->w.materials.size()) return fail(TRT_ERR_INVALID_ARG, "material index out of range");
+    try {
+        w->w.geometries.push_back(Geometry{0u, material, center, trt_vec3{radius, 0.0f, 0.0f}, trt_vec3{0.0f, 0.0f, 0.0f}});
+    } catch (const std::bad_alloc&) {
+        return fail(TRT_ERR_OOM, "out of memory");
+    }
+    return TRT_OK;
+}
+int trt_world_add_quad(trt_world* w, trt_vec3 corner, trt_vec3 u, trt_vec3 v, uint32_t material) {
+    if (!w) return fail(TRT_ERR_INVALID_ARG, "world is null");
+    if (material >= w->w.materials.size()) return fail(TRT_ERR_INVALID_ARG, "material index out of range");
+    try {
+        w->w.geometries.push_back(Geometry{1u, material, corner, u, v});
+    } catch (const std::bad_alloc&) {
+        return fail(TRT_ERR_OOM, "out of memory");
+    }
+    return TRT_OK;
+}
+int trt_world_num_geometries(const trt_world* w) { return w ? (int)w->w.geometries.size() : 0; }
+int trt_world_num_materials(const trt_world* w) { return w ? (int)w->w.materials.size() : 0; }
+
+// ---- Scene ----
+int trt_scene_create(const trt_world* w, trt_scene** out) {
+    if (!w || !out) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    try {
+        trt_scene* s = new trt_scene();
+        std::string msg;
+        if (!compile_scene(w->w, s->host, msg)) { delete s; return fail(TRT_ERR_INVALID_ARG, msg); }
+        *out = s;
+    } catch (const std::bad_alloc&) {
+        return fail(TRT_ERR_OOM, "out of memory");
+    }
+    return TRT_OK;
+}
+void trt_scene_destroy(trt_scene* s) {
+    if (!s) return;
+    for (auto& kv : s->device_blob) {
+        int prev = 0;
+        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(kv.first) == hipSuccess) {
+            (void)hipFree(kv.second);
+            (void)hipSetDevice(prev);
+        }
+    }
+    delete s;
+}
+int trt_scene_get_info(const trt_scene* s, trt_scene_info* out) {
+    if (!s || !out) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    const SceneLayout& L = s->host.layout;
+    out->num_nodes = L.n_nodes; out->num_spheres = L.n_spheres; out->num_quads = L.n_quads; out->num_materials = L.n_materials;
+    out->max_depth = s->host.max_depth;
+    out->device_bytes = L.blob_bytes;
+    out->lds_bytes = L.blob_bytes <= kLdsSceneMaxBytes ? L.blob_bytes : 0;
+    return TRT_OK;
+}
+int trt_scene_get_nodes(const trt_scene* s, float* bbox6, int32_t* prim, int32_t* skip, uint32_t cap) {
+    if (!s || !bbox6 || !prim || !skip) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    uint32_t n = s->host.layout.n_nodes;
+    if (cap < n) return fail(TRT_ERR_INVALID_ARG, "cap is smaller than the node count");
+    for (uint32_t i = 0; i < n; i++) {
+        for (int k = 0; k < 6; k++) bbox6[6 * (size_t)i + k] = s->host.bbox6[6 * (size_t)i + k];
+        prim[i] = s->host.prim_geo[i];
+        skip[i] = s->host.skip[i];
+    }
+    return TRT_OK;
+}
+
+// ---- Camera ----
+int trt_camera_init(trt_camera* out, float focus_distance, float defocus_angle_deg, trt_vec3 position, trt_vec3 look_at,
+                    trt_vec3 up, float vertical_fov_deg, uint32_t width, uint32_t height) {
+    if (!out) return fail(TRT_ERR_INVALID_ARG, "out is null");
+    if (width == 0 || height == 0) return fail(TRT_ERR_INVALID_ARG, "width and height must be positive");
+    camera_init(*out, focus_distance, defocus_angle_deg, position, look_at, up, vertical_fov_deg, width, height);
+    return TRT_OK;
+}
+
+// ---- Renderer::render ----
+int trt_render_device(trt_scene* s, const trt_camera* cam, const trt_render_params* p, float* d_accum, uint64_t* d_counters,
+                      void* stream) {
+    if (!s || !cam || !p || !d_accum) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    int rc = require_device();
+    if (rc != TRT_OK) return rc;
+    return enqueue_render(s, cam, p, d_accum, d_counters, reinterpret_cast<hipStream_t>(stream), nullptr);
+}
+
+int trt_render(trt_scene* s, const trt_camera* cam, const trt_render_params* p, float* accum, trt_stats* stats) {
+    if (!s || !cam || !p || !accum) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    int rc = require_device();
+    if (rc != TRT_OK) return rc;
+    RenderArgs probe;
+    uint32_t rows = 0;
+    rc = to_render_args(cam, p, probe, rows);
+    if (rc != TRT_OK) return rc;
+    const size_t bytes = (size_t)rows * cam->width * 3 * sizeof(float);
+    float* d_accum = nullptr;
+    unsigned long long* d_ctr = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long h_ctr[CTR_COUNT] = {0};
+    float ms = 0.0f;
+    auto cleanup = [&]() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (d_accum) (void)hipFree(d_accum);
+        if (d_ctr) (void)hipFree(d_ctr);
+    };
+#define TRT_HIP_C(call)                                                          \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) { cleanup(); return fail_hip(e_, #call); }         \
+    } while (0)
+    TRT_HIP_C(hipStreamCreate(&stream));
+    TRT_HIP_C(hipEventCreate(&ev0));
+    TRT_HIP_C(hipEventCreate(&ev1));
+    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_accum), bytes ? bytes : 16));
+    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_ctr), sizeof(h_ctr)));
+    TRT_HIP_C(hipMemsetAsync(d_ctr, 0, sizeof(h_ctr), stream));
+    if (p->accumulate && bytes) TRT_HIP_C(hipMemcpyAsync(d_accum, accum, bytes, hipMemcpyHostToDevice, stream));
+    TRT_HIP_C(hipEventRecord(ev0, stream));
+    rc = enqueue_render(s, cam, p, d_accum, reinterpret_cast<uint64_t*>(d_ctr), stream, nullptr);
+    if (rc != TRT_OK) { cleanup(); return rc; }
+    TRT_HIP_C(hipEventRecord(ev1, stream));
+    if (bytes) TRT_HIP_C(hipMemcpyAsync(accum, d_accum, bytes, hipMemcpyDeviceToHost, stream));
+    TRT_HIP_C(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, stream));
+    TRT_HIP_C(hipStreamSynchronize(stream));
+    TRT_HIP_C(hipEventElapsedTime(&ms, ev0, ev1));
+    cleanup();
+    if (stats) { counters_to_stats(h_ctr, stats); stats->kernel_ms = ms; }
+    return TRT_OK;
+}
+
+// ---- Sampler::sampling, batch form ----
+int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_sampled_color* out, uint32_t max_bounces,
+                     trt_vec3 background, uint32_t seed, trt_stats* stats) {
+    if (!s || (n && (!in || !out))) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    int rc = require_device();
+    if (rc != TRT_OK) return rc;
+    if (stats) { *stats = trt_stats{}; }
+    if (n == 0) return TRT_OK;
+    if (max_bounces == 0) {                       // cpu.rs:43-47: the loop body never runs, colour stays 0
+        for (uint32_t i = 0; i < n; i++) { out[i].x = in[i].x; out[i].y = in[i].y; out[i].color = trt_vec3{0.0f, 0.0f, 0.0f}; }
+        if (stats) stats->samples = n;
+        return TRT_OK;
+    }
+    SceneDev sc;
+    rc = scene_on_device(s, sc);
+    if (rc != TRT_OK) return rc;
+    RenderArgs ra{};
+    ra.background[0] = background.x; ra.background[1] = background.y; ra.background[2] = background.z;
+    ra.inv_spp = 1.0f;
+    ra.max_bounces = max_bounces;
+    ra.seed_key = rng_seed_key(seed);
+    trt_sample_point* d_in = nullptr;
+    trt_sampled_color* d_out = nullptr;
+    unsigned long long* d_ctr = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long h_ctr[CTR_COUNT] = {0};
+    float ms = 0.0f;
+    auto cleanup = [&]() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (d_ctr) (void)hipFree(d_ctr);
+    };
+    TRT_HIP_C(hipEventCreate(&ev0));
+    TRT_HIP_C(hipEventCreate(&ev1));
+    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * sizeof(trt_sample_point)));
+    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * sizeof(trt_sampled_color)));
+    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_ctr), sizeof(h_ctr)));
+    TRT_HIP_C(hipMemset(d_ctr, 0, sizeof(h_ctr)));
+    TRT_HIP_C(hipMemcpy(d_in, in, (size_t)n * sizeof(trt_sample_point), hipMemcpyHostToDevice));
+    TRT_HIP_C(hipEventRecord(ev0, nullptr));
+    TRT_HIP_C(launch_sample_batch(sc, d_in, n, d_out, ra, d_ctr, true, nullptr));
+    TRT_HIP_C(hipEventRecord(ev1, nullptr));
+    TRT_HIP_C(hipMemcpy(out, d_out, (size_t)n * sizeof(trt_sampled_color), hipMemcpyDeviceToHost));
+    TRT_HIP_C(hipMemcpy(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost));
+    TRT_HIP_C(hipEventElapsedTime(&ms, ev0, ev1));
+    cleanup();
+    if (stats) { counters_to_stats(h_ctr, stats); stats->kernel_ms = ms; }
+    return TRT_OK;
+#undef TRT_HIP_C
+}
+
+// ---- Imager finalisation ----
+int trt_tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* rgb) {
+    if (npixels && (!accum || !rgb)) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    tonemap_u8(accum, npixels, gamma, rgb);
+    return TRT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// kernels.h — launch interface between the C ABI (capi.hip) and the HIP kernels (kernels.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "scene.h"
+
+namespace trt {
+
+struct SceneDev {
+    const float4* blob;          // packed scene in HBM (scene.h layout)
+    SceneLayout L;
+};
+
+struct CameraDev {               // camera.rs:4-14, the fields get_ray reads
+    float pos[3], upper_left[3], horizontal[3], vertical[3], du[3], dv[3];
+    uint32_t width, height;
+};
+
+struct RenderArgs {
+    float background[3];
+    float inv_spp;               // 1/spp: Imager's color_multiplier (imager.rs:35)
+    uint32_t max_bounces;
+    uint32_t seed_key;           // mix32(seed + 0x9E3779B9)
+    uint32_t sample_begin, sample_end;
+    uint32_t accumulate;
+    uint32_t band_rows, band_stride, band_offset;   // local row -> image row (tinyrt.h)
+    uint32_t rows_local;
+};
+
+// trt-rng v1 per-launch key: mix32(seed + golden ratio), evaluated once on the host.
+inline uint32_t rng_seed_key(uint32_t seed) {
+    uint32_t x = seed + 0x9E3779B9u;
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// counters[0..6] = samples, rays, node_tests, sphere_tests, quad_plane_tests, quad_inside_tests, shades
+enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_COUNT = 8 };
+
+// Largest packed scene the megakernel copies into LDS (one copy per workgroup).
+constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
+
+// Megakernel: whole bounce loop for every pixel of the local rows in one launch.
+hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
+                             unsigned long long* d_counters, bool stats, hipStream_t stream);
+
+// Sampler plug-in form: n caller-supplied rays.
+hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out,
+                               const RenderArgs& ra, unsigned long long* d_counters, bool stats, hipStream_t stream);
+
+}  // namespace trt

@@ -1,0 +1,255 @@
+// rt_device.h — device-side arithmetic of the path-tracing sampler (gfx950 only).
+//
+// f32 throughout (reference: `pub type Float = f32`, raytracer/src/lib.rs:4), written in the
+// reference's expression order and compiled with -ffp-contract=off: Rust never fuses a*b+c,
+// and a sample whose path flips at a hit/miss edge moves a pixel by more than the parity
+// tolerance, so every value that feeds a branch has to be the same float the CPU path gets.
+// Division and sqrt are hipcc's correctly rounded forms (the default for f32 on ROCm 7.2).
+//
+// Two pieces have no counterpart that could be matched bit for bit in the reference and are
+// specified by this project: "trt-rng v1" (xoroshiro64* streams keyed by seed,
+// pixel and sample, standing in for the unseeded rand::thread_rng of utils/random.rs:15-18)
+// and "trt-math v1" (fixed polynomial sin/cos/acos/cbrt standing in for the platform libm
+// behind vec3extend.rs:21-27).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define TRT_DEV __device__ __forceinline__
+
+namespace trt {
+
+// ------------------------------------------------------------------------------------------------
+// Vec3 (math/vec3.rs:18-164): operators keep the reference's association order.
+// ------------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+
+TRT_DEV V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+TRT_DEV V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+TRT_DEV V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+TRT_DEV V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+TRT_DEV V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+TRT_DEV V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+TRT_DEV V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+TRT_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+TRT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // vec3.rs:49-51
+TRT_DEV float sqlen(V3 a) { return dot(a, a); }                                      // vec3.rs:41-43
+TRT_DEV float length(V3 a) { return __builtin_sqrtf(sqlen(a)); }                     // vec3.rs:37-39
+TRT_DEV V3 normalized(V3 a) { return a / length(a); }                                // vec3.rs:45-47 (three divides)
+TRT_DEV V3 cross(V3 a, V3 b) {                                                       // vec3.rs:53-59
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+TRT_DEV bool near_zero(V3 a) {                                                       // vec3.rs:32-35
+    const float eps = 1e-7f;
+    return __builtin_fabsf(a.x) < eps && __builtin_fabsf(a.y) < eps && __builtin_fabsf(a.z) < eps;
+}
+// vec3extend.rs:75-77: v - (2*dot(v,n)) * n
+TRT_DEV V3 reflect(V3 v, V3 n) { return v - (2.0f * dot(v, n)) * n; }
+// vec3extend.rs:79-84
+TRT_DEV V3 refract(V3 v, V3 n, float eta) {
+    float c = __builtin_fminf(-dot(n, v), 1.0f);
+    V3 perp = eta * (v + n * c);
+    V3 parallel = -__builtin_sqrtf(__builtin_fabsf(1.0f - sqlen(perp))) * n;
+    return parallel + perp;
+}
+
+// ------------------------------------------------------------------------------------------------
+// trt-math v1
+// ------------------------------------------------------------------------------------------------
+// sin and cos of x, |x| < 8192: octant reduction by a three-term split of pi/4, then
+// degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4].
+TRT_DEV void dm_sincos(float x, float& sn, float& cs) {
+    const float FOPI = 1.27323954473516f;
+    const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+    float ax = __builtin_fabsf(x);
+    if (!(ax < 8192.0f)) { sn = __builtin_nanf(""); cs = sn; return; }
+    uint32_t j = (uint32_t)(ax * FOPI);
+    j = (j + 1u) & ~1u;
+    float y = (float)j;
+    float r = ((ax - y * DP1) - y * DP2) - y * DP3;
+    float z = r * r;
+    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z + -1.6666654611e-1f) * z * r + r;
+    float pc = ((2.443315711809948e-5f * z + -1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z;
+    pc = (pc - 0.5f * z) + 1.0f;
+    uint32_t q = (j >> 1) & 3u;
+    float s = (q & 1u) ? pc : ps;
+    float c = (q & 1u) ? ps : pc;
+    s = (q & 2u) ? -s : s;                  // q: 0 (ps,pc) 1 (pc,-ps) 2 (-ps,-pc) 3 (-pc,ps)
+    c = ((q + 1u) & 2u) ? -c : c;
+    sn = (x < 0.0f) ? -s : s;
+    cs = c;
+}
+
+TRT_DEV float dm_asin_poly(float z) {
+    return (((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
+           + 1.6666752422e-1f;
+}
+
+TRT_DEV float dm_acos(float x) {
+    const float PI_F = 3.14159265358979323846f, PIO2_F = 1.57079632679489661923f;
+    if (x > 0.5f) {
+        float z = 0.5f * (1.0f - x);
+        float s = __builtin_sqrtf(z);
+        float r = dm_asin_poly(z) * z * s + s;
+        return r + r;
+    }
+    if (x < -0.5f) {
+        float z = 0.5f * (1.0f + x);
+        float s = __builtin_sqrtf(z);
+        float r = dm_asin_poly(z) * z * s + s;
+        return PI_F - (r + r);
+    }
+    float z = x * x;
+    float r = dm_asin_poly(z) * z * x + x;
+    return PIO2_F - r;
+}
+
+// cube root: exponent/3 bit guess, two Halley steps; the second in residual form (< 1 ulp).
+TRT_DEV float dm_cbrt(float x) {
+    uint32_t ux = __float_as_uint(x);
+    uint32_t sign = ux & 0x80000000u;
+    uint32_t ua = ux & 0x7fffffffu;
+    if (ua == 0u || ua >= 0x7f800000u) return x;
+    float a = __uint_as_float(ua);
+    float scale = 1.0f;
+    if (ua < 0x00800000u) { a = a * 16777216.0f; scale = 0.00390625f; ua = __float_as_uint(a); }
+    float y = __uint_as_float(ua / 3u + 0x2a5137a0u);
+    float y3 = y * y * y;
+    y = y * ((y3 + (a + a)) / ((y3 + y3) + a));
+    y3 = y * y * y;
+    y = y + y * ((a - y3) / ((y3 + y3) + a));
+    y = y * scale;
+    return __uint_as_float(__float_as_uint(y) | sign);
+}
+
+// ------------------------------------------------------------------------------------------------
+// trt-rng v1: one xoroshiro64* stream per (seed, pixel, sample), drawn in the reference's order.
+// ------------------------------------------------------------------------------------------------
+struct Rng { uint32_t s0, s1; };
+
+TRT_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// seed_key = mix32(seed + 0x9E3779B9), the same for every lane of a launch (computed on the host).
+TRT_DEV Rng rng_seed(uint32_t seed_key, uint32_t pixel, uint32_t sample) {
+    Rng r;
+    r.s0 = mix32(sample + mix32(pixel ^ seed_key));
+    r.s1 = mix32(pixel + mix32(sample ^ ~seed_key));
+    if ((r.s0 | r.s1) == 0u) r.s1 = 0x6C078965u;
+    return r;
+}
+TRT_DEV uint32_t rng_next(Rng& g) {
+    uint32_t s0 = g.s0, s1 = g.s1;
+    uint32_t r = s0 * 0x9E3779BBu;
+    s1 ^= s0;
+    g.s0 = __builtin_rotateleft32(s0, 26) ^ s1 ^ (s1 << 9);
+    g.s1 = __builtin_rotateleft32(s1, 13);
+    return r;
+}
+// random::<f32>() (utils/random.rs:11-13): 23 mantissa bits into [1,2), minus 1.
+TRT_DEV float rng_random(Rng& g) { return __uint_as_float(0x3f800000u | (rng_next(g) >> 9)) - 1.0f; }
+// random_range(lo..hi) (utils/random.rs:15-18)
+TRT_DEV float rng_range(Rng& g, float lo, float hi) {
+    float v01 = __uint_as_float(0x3f800000u | (rng_next(g) >> 9)) - 1.0f;
+    return v01 * (hi - lo) + lo;
+}
+
+// vec3extend.rs:15-30
+TRT_DEV V3 random_in_unit_sphere(Rng& g) {
+    float u1 = rng_random(g);
+    float u2 = rng_random(g);
+    float u3 = rng_random(g);
+    float theta = (2.0f * 3.14159265358979323846f) * u1;
+    float phi = dm_acos(1.0f - 2.0f * u2);
+    float r = dm_cbrt(u3);
+    float sin_phi, cos_phi, sin_theta, cos_theta;
+    dm_sincos(phi, sin_phi, cos_phi);
+    dm_sincos(theta, sin_theta, cos_theta);
+    float x = r * sin_phi * cos_theta;
+    float y = r * sin_phi * sin_theta;
+    float z = r * cos_phi;
+    return v3(x, y, z);
+}
+// vec3extend.rs:32-34
+TRT_DEV V3 random_unit_vector(Rng& g) { return normalized(random_in_unit_sphere(g)); }
+// vec3extend.rs:45-53 (rejection loop; z stays 0)
+TRT_DEV void random_in_unit_disk(Rng& g, float& px, float& py) {
+    for (;;) {
+        px = rng_range(g, -1.0f, 1.0f);
+        py = rng_range(g, -1.0f, 1.0f);
+        if (px * px + py * py < 1.0f) return;          // squared_length with z = 0
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ray (ray.rs): direction is normalised on construction (ray.rs:12-14).
+// ------------------------------------------------------------------------------------------------
+struct Ray { V3 o, d; };
+TRT_DEV Ray ray_new(V3 o, V3 d) { return Ray{o, normalized(d)}; }
+TRT_DEV V3 ray_at(const Ray& r, float t) { return r.o + t * r.d; }                   // ray.rs:24-26
+
+// ------------------------------------------------------------------------------------------------
+// AABB slab test (hittable/aabb.rs:36-61).
+//
+// slab_exact is the reference's compare-and-assign sequence, NaN behaviour included (a zero
+// direction component on a box face gives 0*inf = NaN, which the reference's `<` tests leave
+// untouched).  The per-axis early return is dropped: start only grows and end only shrinks, and
+// neither can become NaN, so `end <= start` after the third axis decides the same way.
+//
+// slab_fast needs 1/d and the origin finite (checked once per ray): then no t is NaN, the
+// reference's swap is min/max of the two plane distances, and the assignments are max/min.
+// ------------------------------------------------------------------------------------------------
+TRT_DEV bool slab_exact(float4 na, float4 nb, V3 o, V3 inv, float start, float end) {
+    float t0, t1, tmp;
+    t0 = (na.x - o.x) * inv.x; t1 = (na.w - o.x) * inv.x;
+    if (t1 < t0) { tmp = t0; t0 = t1; t1 = tmp; }
+    if (start < t0) start = t0;
+    if (t1 < end) end = t1;
+    t0 = (na.y - o.y) * inv.y; t1 = (nb.x - o.y) * inv.y;
+    if (t1 < t0) { tmp = t0; t0 = t1; t1 = tmp; }
+    if (start < t0) start = t0;
+    if (t1 < end) end = t1;
+    t0 = (na.z - o.z) * inv.z; t1 = (nb.y - o.z) * inv.z;
+    if (t1 < t0) { tmp = t0; t0 = t1; t1 = tmp; }
+    if (start < t0) start = t0;
+    if (t1 < end) end = t1;
+    return !(end <= start);
+}
+
+TRT_DEV bool slab_fast(float4 na, float4 nb, V3 o, V3 inv, float start, float end) {
+    float x0 = (na.x - o.x) * inv.x, x1 = (na.w - o.x) * inv.x;
+    float y0 = (na.y - o.y) * inv.y, y1 = (nb.x - o.y) * inv.y;
+    float z0 = (na.z - o.z) * inv.z, z1 = (nb.y - o.z) * inv.z;
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+    start = __builtin_fmaxf(start, tn);
+    end = __builtin_fminf(end, tf);
+    return !(end <= start);
+}
+
+TRT_DEV bool finite_f(float v) { return __builtin_fabsf(v) < __builtin_inff(); }
+
+// ------------------------------------------------------------------------------------------------
+// Primitive tests.  Range<f32>::contains is half open: t0 <= t < t1.
+// ------------------------------------------------------------------------------------------------
+// Sphere::hit (hittable/sphere.rs:29-54).  sp = (center.xyz, radius).
+TRT_DEV bool sphere_test(float4 sp, const Ray& ray, float t0, float t1, float& t_out) {
+    V3 oc = ray.o - v3(sp.x, sp.y, sp.z);
+    float a = sqlen(ray.d);
+    float half_b = dot(oc, ray.d);
+    float c = sqlen(oc) - sp.w * sp.w;
+    float disc = half_b * half_b - a * c;
+    if (disc < 0.0f) return false;
+    float sqrtd = __builtin_sqrtf(disc);
+    float t = (-half_b - sqrtd) / a;
+    if (!(t0 <= t && t < t1)) {
+        t = (-half_b + sqrtd) / a;
+        if (!(t0 <= t && t < t1)) return false;
+    }
+    t_out = t;
+    return true;
+}
+
+}  // namespace trt

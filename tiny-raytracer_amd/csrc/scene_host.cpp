@@ -1,0 +1,249 @@
+// scene_host.cpp — host side of the path: World -> reference-order BVH -> packed pre-order scene,
+// Camera::new, and the Imager's gamma/quantise step.  Plain C++ (no device code); compiled with
+// -ffp-contract=off so the f32 values it precomputes (boxes, quad planes, camera basis) are the
+// ones the reference's constructors produce.
+#include "scene.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace trt {
+namespace {
+
+struct H3 { float x, y, z; };
+inline H3 h3(trt_vec3 v) { return H3{v.x, v.y, v.z}; }
+inline H3 operator+(H3 a, H3 b) { return H3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline H3 operator-(H3 a, H3 b) { return H3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline H3 operator*(H3 a, float s) { return H3{a.x * s, a.y * s, a.z * s}; }
+inline H3 operator/(H3 a, float s) { return H3{a.x / s, a.y / s, a.z / s}; }
+inline float hdot(H3 a, H3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline H3 hcross(H3 a, H3 b) { return H3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline H3 hnormalized(H3 a) { return a / sqrtf(hdot(a, a)); }                   // vec3.rs:45-47
+inline H3 hmin(H3 a, H3 b) { return H3{fminf(a.x, b.x), fminf(a.y, b.y), fminf(a.z, b.z)}; }   // vec3extend.rs:59-65
+inline H3 hmax(H3 a, H3 b) { return H3{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z)}; }   // vec3extend.rs:67-73
+
+struct Box { H3 lo, hi; };
+
+// AABB::new: the two corners ordered per axis, then grown by PADDING_AMOUNT/2 (aabb.rs:13-20)
+Box box_from_corners(H3 a, H3 b) {
+    const float pad = 0.0001f / 2.0f;
+    H3 p{pad, pad, pad};
+    return Box{hmin(a, b) - p, hmax(a, b) + p};
+}
+Box box_union(Box a, Box b) { return Box{hmin(a.lo, b.lo), hmax(a.hi, b.hi)}; }                // aabb.rs:30-34
+
+// AABB::longest_axis (aabb.rs:63-78): ties go to the later axis.
+int box_longest_axis(const Box& b) {
+    float sx = b.hi.x - b.lo.x, sy = b.hi.y - b.lo.y, sz = b.hi.z - b.lo.z;
+    if (sx > sy) return sx > sz ? 0 : 2;
+    return sy > sz ? 1 : 2;
+}
+inline float axis_of(H3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// f32::total_cmp as an integer key (aabb.rs:80-82)
+inline int32_t total_order_key(float f) {
+    int32_t bits;
+    memcpy(&bits, &f, 4);
+    return bits ^ (int32_t)((uint32_t)(bits >> 31) >> 1);
+}
+
+inline float bitsf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+struct Builder {
+    const std::vector<Box>& prim_box;
+    std::vector<Box> node_box;
+    std::vector<int32_t> node_prim;
+    std::vector<int32_t> node_skip;
+    uint32_t max_depth = 0;
+
+    explicit Builder(const std::vector<Box>& pb) : prim_box(pb) {}
+
+    // Node::new (bvh.rs:42-84), emitting nodes in pre-order.  Returns the node's index.
+    uint32_t build(const uint32_t* objs, size_t n, uint32_t depth) {
+        uint32_t me = (uint32_t)node_box.size();
+        node_box.push_back(Box{});
+        node_prim.push_back(-1);
+        node_skip.push_back(0);
+        if (depth > max_depth) max_depth = depth;
+        if (n == 1) {
+            node_box[me] = prim_box[objs[0]];
+            node_prim[me] = (int32_t)objs[0];
+        } else if (n == 2) {                     // children keep the given order: no sort (bvh.rs:58-67)
+            uint32_t l = build(objs, 1, depth + 1);
+            uint32_t r = build(objs + 1, 1, depth + 1);
+            node_box[me] = box_union(node_box[l], node_box[r]);
+        } else {
+            Box all = prim_box[objs[0]];
+            for (size_t i = 1; i < n; i++) all = box_union(all, prim_box[objs[i]]);
+            int axis = box_longest_axis(all);
+            std::vector<uint32_t> sorted(objs, objs + n);
+            std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
+                return total_order_key(axis_of(prim_box[a].lo, axis)) < total_order_key(axis_of(prim_box[b].lo, axis));
+            });
+            size_t mid = n / 2;
+            uint32_t l = build(sorted.data(), mid, depth + 1);
+            uint32_t r = build(sorted.data() + mid, n - mid, depth + 1);
+            node_box[me] = box_union(node_box[l], node_box[r]);
+        }
+        node_skip[me] = (int32_t)node_box.size();
+        return me;
+    }
+};
+
+inline bool tame(float v) { return fabsf(v) < 1e30f; }
+inline bool tame3(H3 v) { return tame(v.x) && tame(v.y) && tame(v.z); }
+
+}  // namespace
+
+bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
+    const size_t ng = w.geometries.size();
+    if (ng == 0) { msg = "world has no geometry"; return false; }
+    if (ng > PRIM_INDEX_MASK) { msg = "too many geometries"; return false; }
+
+    // per-primitive constructor work: Sphere::new (sphere.rs:16-26), Quad::new (quad.rs:20-29)
+    std::vector<Box> prim_box(ng);
+    std::vector<uint32_t> local_index(ng);
+    std::vector<F4> spheres, q0, q1, q2, q3, q4;
+    std::vector<uint32_t> sphere_mat;
+    bool all_finite = true;
+    for (size_t g = 0; g < ng; g++) {
+        const Geometry& geo = w.geometries[g];
+        if (geo.material >= w.materials.size()) { msg = "geometry refers to a material index that does not exist"; return false; }
+        if (geo.kind == 0) {
+            H3 c = h3(geo.a);
+            float r = geo.b.x;
+            H3 rv{r, r, r};
+            prim_box[g] = box_from_corners(c - rv, c + rv);
+            local_index[g] = (uint32_t)spheres.size();
+            spheres.push_back(F4{c.x, c.y, c.z, r});
+            sphere_mat.push_back(geo.material);
+            all_finite = all_finite && tame3(c) && tame(r);
+        } else {
+            H3 corner = h3(geo.a), u = h3(geo.b), v = h3(geo.c);
+            prim_box[g] = box_union(box_from_corners(corner, (corner + u) + v), box_from_corners(corner + u, corner + v));
+            H3 n = hcross(u, v);
+            H3 wv = n / hdot(n, n);
+            float d = hdot(n, corner);
+            H3 nu = hnormalized(n);              // HitRecord::new normalises per hit (mod.rs:35-40): same value, once
+            local_index[g] = (uint32_t)q0.size();
+            q0.push_back(F4{n.x, n.y, n.z, d});
+            q1.push_back(F4{corner.x, corner.y, corner.z, bitsf(geo.material)});
+            q2.push_back(F4{v.x, v.y, v.z, wv.x});
+            q3.push_back(F4{wv.y, wv.z, u.x, u.y});
+            q4.push_back(F4{u.z, nu.x, nu.y, nu.z});
+            all_finite = all_finite && tame3(corner) && tame3(u) && tame3(v) && tame3(n) && tame(d);
+        }
+        all_finite = all_finite && tame3(prim_box[g].lo) && tame3(prim_box[g].hi);
+    }
+
+    // BVH::new (bvh.rs:12-22): objects in insertion order
+    std::vector<uint32_t> order(ng);
+    for (size_t g = 0; g < ng; g++) order[g] = (uint32_t)g;
+    Builder b(prim_box);
+    b.node_box.reserve(2 * ng);
+    b.node_prim.reserve(2 * ng);
+    b.node_skip.reserve(2 * ng);
+    b.build(order.data(), ng, 1);
+
+    const uint32_t nn = (uint32_t)b.node_box.size();
+    const uint32_t ns = (uint32_t)spheres.size(), nq = (uint32_t)q0.size(), nm = (uint32_t)w.materials.size();
+    SceneLayout& L = out.layout;
+    L.n_nodes = nn; L.n_spheres = ns; L.n_quads = nq; L.n_materials = nm;
+    L.off_node_b = nn;
+    L.off_sphere = 2 * nn;
+    L.off_quad = L.off_sphere + ns;
+    L.off_material = L.off_quad + 5 * nq;
+    uint32_t n_f4 = L.off_material + nm;
+    L.off_sphere_mat = n_f4 * 4;
+    L.off_material_kind = L.off_sphere_mat + ns;
+    uint32_t n_u32 = L.off_material_kind + nm;
+    L.blob_bytes = ((n_u32 * 4u) + 15u) & ~15u;
+    L.all_finite = all_finite ? 1u : 0u;
+
+    out.blob.assign(L.blob_bytes, 0);
+    F4* f4 = reinterpret_cast<F4*>(out.blob.data());
+    uint32_t* u32 = reinterpret_cast<uint32_t*>(out.blob.data());
+    out.bbox6.resize(6 * (size_t)nn);
+    out.prim_geo = b.node_prim;
+    out.skip = b.node_skip;
+    for (uint32_t i = 0; i < nn; i++) {
+        const Box& bx = b.node_box[i];
+        uint32_t prim = PRIM_NONE;
+        if (b.node_prim[i] >= 0) {
+            const Geometry& geo = w.geometries[(size_t)b.node_prim[i]];
+            prim = local_index[(size_t)b.node_prim[i]] | (geo.kind == 1 ? PRIM_QUAD_BIT : 0u);
+        }
+        f4[i] = F4{bx.lo.x, bx.lo.y, bx.lo.z, bx.hi.x};
+        f4[L.off_node_b + i] = F4{bx.hi.y, bx.hi.z, bitsf((uint32_t)b.node_skip[i]), bitsf(prim)};
+        float* o = &out.bbox6[6 * (size_t)i];
+        o[0] = bx.lo.x; o[1] = bx.lo.y; o[2] = bx.lo.z; o[3] = bx.hi.x; o[4] = bx.hi.y; o[5] = bx.hi.z;
+    }
+    for (uint32_t i = 0; i < ns; i++) { f4[L.off_sphere + i] = spheres[i]; u32[L.off_sphere_mat + i] = sphere_mat[i]; }
+    for (uint32_t i = 0; i < nq; i++) {
+        f4[L.off_quad + 0 * nq + i] = q0[i];
+        f4[L.off_quad + 1 * nq + i] = q1[i];
+        f4[L.off_quad + 2 * nq + i] = q2[i];
+        f4[L.off_quad + 3 * nq + i] = q3[i];
+        f4[L.off_quad + 4 * nq + i] = q4[i];
+    }
+    for (uint32_t i = 0; i < nm; i++) {
+        const trt_material& m = w.materials[i];
+        f4[L.off_material + i] = F4{m.albedo.x, m.albedo.y, m.albedo.z, m.param};
+        u32[L.off_material_kind + i] = m.kind;
+    }
+    out.max_depth = b.max_depth;
+    return true;
+}
+
+// Camera::new (camera.rs:17-56).  f32::to_radians multiplies by the f32 constant PI/180.
+void camera_init(trt_camera& out, float focus_distance, float defocus_angle_deg, trt_vec3 position, trt_vec3 look_at,
+                 trt_vec3 up, float vertical_fov_deg, uint32_t width, uint32_t height) {
+    const float rad_per_deg = 3.14159265358979323846f / 180.0f;
+    float viewport_height = 2.0f * focus_distance * tanf((vertical_fov_deg * rad_per_deg) / 2.0f);
+    float aspect_ratio = (float)width / (float)height;
+    float viewport_width = aspect_ratio * viewport_height;
+
+    H3 pos = h3(position);
+    H3 w = hnormalized(pos - h3(look_at));
+    H3 u = hnormalized(hcross(h3(up), w));
+    H3 v = hnormalized(hcross(w, u));
+
+    H3 forward = w * focus_distance;
+    H3 horizontal = u * viewport_width;
+    H3 vertical = v * viewport_height;
+    H3 upper_left = ((pos - horizontal / 2.0f) + vertical / 2.0f) - forward;
+
+    float defocus_radius = focus_distance * tanf((defocus_angle_deg * rad_per_deg) / 2.0f);
+    H3 du = u * defocus_radius, dv = v * defocus_radius;
+
+    out.position = position;
+    out.viewport_upper_left = trt_vec3{upper_left.x, upper_left.y, upper_left.z};
+    out.forward = trt_vec3{forward.x, forward.y, forward.z};
+    out.horizontal = trt_vec3{horizontal.x, horizontal.y, horizontal.z};
+    out.vertical = trt_vec3{vertical.x, vertical.y, vertical.z};
+    out.defocus_disk_u = trt_vec3{du.x, du.y, du.z};
+    out.defocus_disk_v = trt_vec3{dv.x, dv.y, dv.z};
+    out.width = width;
+    out.height = height;
+}
+
+// Imager: set_pixel applies gamma (imager.rs:52-53, image.rs:38-44,92-98); RgbImage conversion clamps
+// to [0, 0.999], scales by 255 and truncates (image.rs:101-111; Rust's `as u8` saturates, NaN -> 0).
+void tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* rgb) {
+    const float inv_gamma = 1.0f / gamma;
+    for (size_t i = 0; i < (size_t)npixels * 3; i++) {
+        float c = powf(accum[i], inv_gamma);
+        if (c < 0.000f) c = 0.000f;
+        if (c > 0.999f) c = 0.999f;
+        float s = c * 255.0f;
+        uint8_t q;
+        if (!(s == s) || s <= 0.0f) q = 0;
+        else if (s >= 255.0f) q = 255;
+        else q = (uint8_t)s;
+        rgb[i] = q;
+    }
+}
+
+}  // namespace trt
