@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline metric on MI355X: Mray/s (primary + secondary rays) of the path-tracing
+hot path on the Cornell box at 2048x2048, depth 50 (BASELINE.json configs[3]; it fits one GPU), plus the dominant
+kernel's algorithmic-byte rate against the HBM roofline and the CPU oracle timed on this box's host cores.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of --spp-per-step samples per pixel over the whole image, continuing the running f32 sums that
+stay resident in HBM (the full config's 4096 spp is 256 such steps of 16).  With N > 1 the image's 16-row bands are
+dealt round-robin to the ranks (strong scaling: the image is fixed), every rank runs the same steps on its rows, and
+one RCCL gather of the accumulators to rank 0 closes the frame inside the timed region.  Rays are counted on the
+device (one ray = one closest-hit query = one `world.hit` call, reference cpu.rs:48).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); 6290 measured-achievable
+
+
+def algorithmic_bytes(c, pixels):
+    """bytes the reference-order traversal has to read, + 12 B per pixel written per launch."""
+    return (32 * c["node_tests"] + 16 * c["sphere_tests"] + 16 * c["quad_plane_tests"] + 48 * c["quad_inside_tests"]
+            + 20 * c["shades"] + 12 * pixels)
+
+
+def cpu_baseline(trt, desc, depth, budget_s):
+    """The CPU oracle (a port of the reference's CPU path) on a bounded sample of the same workload: whole-image
+    passes of 1 spp, all host cores, until `budget_s` seconds have been spent."""
+    from oracle import orc
+    import numpy as np
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    world, cam = orc.world_from_description(desc)
+    orc.lib.orc_world_build(world._h)
+    acc = np.zeros((cam.height, cam.width, 3), np.float32)
+    rays = 0
+    spp_done = 0
+    t0 = time.perf_counter()
+    while True:
+        _, st = orc.render(world, cam, 4096, depth, desc["background"], seed=1, nthreads=cores, sample_begin=spp_done,
+                           sample_end=spp_done + 1, accum=acc)
+        rays += st["rays"]
+        spp_done += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or spp_done >= 64:
+            break
+    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+            "sample": f"{spp_done} spp of the {cam.width}x{cam.height} depth-{depth} frame ({rays} rays, {dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=2048)
+    ap.add_argument("--depth", type=int, default=50)
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "random_spheres", "sphere_grid"])
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the untimed counter pass")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_size != args.gpus:
+        if world_size == 1 and args.gpus > 1:
+            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world_size
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    trt = importlib.import_module("tiny-raytracer_amd")
+    tiles = importlib.import_module("tiny-raytracer_amd.tiles")
+    trt._lib.check(trt.lib.trt_set_device(local_rank))
+
+    W, H = args.width, args.height
+    desc = {"cornell": trt.scenes.cornell, "random_spheres": trt.scenes.random_spheres,
+            "sphere_grid": lambda w, h: trt.scenes.sphere_grid(100000, w, h)}[args.scene](W, H)
+    world, cam = trt.world_from_description(desc)
+    scene = world.get_bvh()
+    total_spp = 4096
+    renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1)
+
+    lay = tiles.band_layout(H, world_size, rank)
+    band = dict(band_rows=lay["band_rows"], band_stride=lay["band_stride"], band_offset=lay["band_offset"],
+                rows_local=lay["rows_local"]) if world_size > 1 else {}
+    rows_local = lay["rows_local"]
+    acc = torch.zeros((rows_local, W, 3), dtype=torch.float32, device=dev)
+    ctr = torch.zeros(8, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+    S = args.spp_per_step
+
+    def step(i, stats=False, counters=ctr, target=acc):
+        renderer.render_device(cam, scene, target.data_ptr(), stream.cuda_stream, counters.data_ptr(),
+                               sample_begin=i * S, sample_end=(i + 1) * S, accumulate=1, collect_stats=1 if stats else 0,
+                               **band)
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    if world_size > 1:                                  # warm the RCCL gather too
+        tiles.gather_image(acc, H, W, world_size, rank)
+    barrier()
+    ctr.zero_()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        step(args.warmup + k)
+        ev[k][1].record(stream)
+    frame = tiles.gather_image(acc, H, W, world_size, rank)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    counts = ctr.clone()
+    if world_size > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_rays = int(counts[1].item())
+    total_samples = int(counts[0].item())
+    launch_ms = [a.elapsed_time(b) for a, b in ev]
+
+    roofline = None
+    if not args.no_roofline_pass:
+        # untimed: the same K launches with the counting kernel variant -> exact algorithmic bytes of those launches
+        sctr = torch.zeros(8, dtype=torch.int64, device=dev)
+        scratch = torch.zeros_like(acc)
+        for k in range(args.steps):
+            step(args.warmup + k, stats=True, counters=sctr, target=scratch)
+        torch.cuda.synchronize()
+        c = dict(zip(("samples", "rays", "node_tests", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"),
+                     [int(v) for v in sctr[:7].tolist()]))
+        assert c["rays"] == int(ctr[1].item()), "counting variant traced a different number of rays"
+        bytes_per_launch = algorithmic_bytes(c, 0) / args.steps + 12 * rows_local * W
+        avg_ms = sum(launch_ms) / len(launch_ms)
+        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(prof):
+            with open(prof) as f:
+                pj = json.load(f)
+            key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}"
+            traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
+        roofline = {"bound": "hbm", "kernel": "trt::megakernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4),
+                    "bytes_per_ray": round(algorithmic_bytes(c, 0) / max(c["rays"], 1), 2),
+                    "rays_per_sample": round(c["rays"] / max(c["samples"], 1), 3)}
+
+    cpu = None
+    if rank == 0 and world_size == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(trt, desc, args.depth, args.cpu_seconds)
+
+    if rank == 0:
+        if frame is not None:
+            assert tuple(frame.shape) == (H, W, 3)
+        out = {
+            "metric": "Mray/s (primary+secondary)", "value": round(total_rays / elapsed / 1e6, 2), "unit": "Mray/s",
+            "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.scene} {W}x{H}, depth {args.depth}, {S} spp per step (of 4096), "
+                                   f"megakernel, reference-order BVH, seed 1",
+                       "rays": total_rays, "samples": total_samples, "image_rows_per_gpu": rows_local,
+                       "parallelism": f"image bands x{world_size}" if world_size > 1 else "single GPU"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world_size > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

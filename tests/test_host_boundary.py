@@ -1,0 +1,135 @@
+"""CPU-side checks of the product: the C ABI library loads and exports every symbol include/tinyrt.h declares,
+POD layouts match the reference's #[repr(C)] structs, the host scene compiler reproduces the reference's BVH
+(compared with the oracle's pointer tree), Camera::new matches, errors come back as codes.  No compute calls:
+those need a GPU and live in test_gpu_parity.py."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+from conftest import sym
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(trt):
+    header = open(os.path.join(ROOT, "include", "tinyrt.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(trt_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 20
+    from importlib import import_module
+    _lib = import_module("tiny-raytracer_amd._lib")
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(raw, name), f"{name} declared in tinyrt.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes table and header disagree"
+    assert trt.lib.trt_abi_version() == 1
+
+
+def test_pod_layouts_match_reference(trt):
+    # Vec3 12 B, Ray 24 B, SamplePoint 32 B (pointgen.rs:7-13), SampledColor 20 B (imager.rs:9-15)
+    assert C.sizeof(trt.Vec3) == 12 and C.sizeof(trt.Ray) == 24
+    assert C.sizeof(trt.SamplePoint) == 32 and C.sizeof(trt.SampledColor) == 20
+    assert trt.SamplePoint.ray.offset == 8 and trt.SampledColor.color.offset == 8
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "tiny-raytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                text = open(os.path.join(dirpath, fn), errors="replace").read()
+                assert "rt_oracle" not in text and "liboracle" not in text and "oracle." not in text.replace("oracle wrapper", ""), fn
+
+
+@pytest.mark.parametrize("scene", ["cornell", "dummy", "quad_test", "random_spheres", "grid3000"])
+def test_scene_compiler_reproduces_reference_bvh(trt, orc, scene):
+    desc = {"cornell": lambda: trt.scenes.cornell(), "dummy": lambda: trt.scenes.dummy_spheres("renderer"),
+            "quad_test": lambda: trt.scenes.quad_test(), "random_spheres": lambda: trt.scenes.random_spheres(),
+            "grid3000": lambda: trt.scenes.sphere_grid(3000, 64, 36)}[scene]()
+    pw, pcam = trt.world_from_description(desc)
+    ow, ocam = orc.world_from_description(desc)
+    bbox, prim, skip = pw.get_bvh().nodes()
+    obox, oprim, osub = ow.bvh_dump()
+    n = len(desc["geometries"])
+    assert len(prim) == 2 * n - 1                                  # one primitive per leaf (bvh.rs:49-57)
+    assert np.array_equal(bbox.view(np.uint32), obox.view(np.uint32))
+    assert np.array_equal(prim, oprim)
+    assert np.array_equal(skip, np.arange(len(skip)) + osub)       # skip link = pre-order index after the subtree
+    assert sorted(prim[prim >= 0].tolist()) == list(range(n))
+    assert bytes(pcam.pod) == bytes(ocam)                          # Camera::new, bit for bit
+    info = pw.get_bvh().info()
+    assert info["num_nodes"] == 2 * n - 1 and info["num_spheres"] + info["num_quads"] == n
+
+
+def test_camera_new_kat_through_c_abi(trt, golden):
+    g = golden["camera_new"]
+    cam = trt.Camera(g["focus_distance"], g["defocus_angle"], sym(g["position"]), sym(g["look_at"]), sym(g["up"]),
+                     g["vertical_fov"], g["width"], g["height"])
+    for field, expected in g["expected"].items():
+        got = np.array(getattr(cam.pod, field).tolist())
+        assert np.abs(got - np.array(sym(expected))).max() < 1e-6, field       # reference asserts with tolerant ==
+    assert cam.get_image_size() == (16, 9)
+
+
+def test_world_errors_are_codes_not_panics(trt):
+    w = trt.World()
+    w.add_material("red", trt.Lambertian((1, 0, 0)))
+    with pytest.raises(trt.TinyRTError) as e:                      # world.rs:29-31 panics here
+        w.add_material("red", trt.Lambertian((0, 1, 0)))
+    assert e.value.code == -2 and "already in the material table" in str(e.value)
+    assert w.get_material("nope") is None                          # world.rs:35-41 -> None
+    assert w.get_material("red") == 0
+    with pytest.raises(trt.TinyRTError):
+        w.add_geometry(trt.Sphere((0, 0, 0), 1.0, 7))              # dangling material handle
+    with pytest.raises(trt.TinyRTError) as e:
+        w.get_bvh()                                                # empty world: BVH::new would index objects[0]
+    assert e.value.code == -1
+    with pytest.raises(trt.TinyRTError):
+        trt.Camera(1.0, 0.0, (0, 0, 0), (0, 0, 1), (0, 1, 0), 90.0, 0, 9)
+
+
+def test_metal_fuzz_is_clamped_like_metal_new(trt, orc):
+    # Metal::new clamps fuzz to [0,1] (metal.rs:12-14); checked through the packed scene
+    desc = dict(materials=[("m", 1, (0.5, 0.5, 0.5), 7.0)], geometries=[("sphere", (0, 0, 0), 1.0, "m")],
+                camera=dict(focus_distance=1.0, defocus_angle=0.0, position=(0, 0, 3), look_at=(0, 0, 0), up=(0, 1, 0),
+                            vertical_fov=40.0, width=4, height=4))
+    pw, _ = trt.world_from_description(desc)
+    assert pw.get_bvh().info()["num_materials"] == 1
+
+
+def test_compute_calls_fail_loudly_without_a_gpu(trt):
+    if trt.lib.trt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    w, cam = trt.world_from_description(trt.scenes.cornell(16, 16))
+    with pytest.raises(trt.TinyRTError) as e:
+        trt.Renderer(1, 1, 2, False, (0, 0, 0)).render(cam, w)
+    assert e.value.code == -5                                      # TRT_ERR_NO_DEVICE: no CPU fallback exists
+
+
+def test_tonemap_matches_oracle_and_reference_rules(trt, orc):
+    rng = np.random.default_rng(0)
+    acc = rng.uniform(-0.2, 1.4, (17, 9, 3)).astype(np.float32)
+    acc[0, 0] = [np.nan, 0.0, 1.0]
+    acc[0, 1] = [np.inf, -np.inf, 0.999 ** 2.2]
+    mine = trt.Image(acc).to_u8()
+    ref = orc.tonemap_u8(acc)
+    assert np.array_equal(mine, ref)
+    assert mine[0, 0].tolist() == [0, 0, 254]                      # NaN -> 0 (image.rs:106-108), clamp at 0.999
+    assert mine.max() == 254
+
+
+def test_band_layout_covers_image_once(trt):
+    from importlib import import_module
+    tiles = import_module("tiny-raytracer_amd.tiles")
+    for height in (1, 15, 16, 17, 100, 2048):
+        for ws in (1, 2, 3, 8):
+            rows = []
+            for r in range(ws):
+                lay = tiles.band_layout(height, ws, r)
+                assert lay["rows_local"] == len(lay["rows"])
+                for local, y in enumerate(lay["rows"]):          # the mapping documented in tinyrt.h
+                    assert y == ((local // 16) * ws + r) * 16 + local % 16
+                rows += lay["rows"]
+            assert sorted(rows) == list(range(height))

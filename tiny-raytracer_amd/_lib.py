@@ -108,7 +108,27 @@ def build(force=False):
     return LIB_PATH
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same SONAMEs as /opt/rocm's).
+    Two HSA runtimes in one process cannot both own the GPU, so when torch is installed its copy is mapped first
+    and libtinyrt.so (DT_NEEDED libamdhip64.so.7) binds to that one: device pointers and streams handed over
+    from torch then belong to the same runtime.  Without torch the system ROCm runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        return cand
+    return None
+
+
 def load():
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()' "
