@@ -7,7 +7,7 @@ kernel's algorithmic-byte rate against the HBM roofline and the CPU oracle timed
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of --spp-per-step samples per pixel over the whole image, continuing the running f32 sums that
-stay resident in HBM (the full config's 4096 spp is 256 such steps of 16).  With N > 1 the image's 16-row bands are
+stay resident in HBM (the full config's 4096 spp is 64 such steps of 64).  With N > 1 the image's 16-row bands are
 dealt round-robin to the ranks (strong scaling: the image is fixed), every rank runs the same steps on its rows, and
 one RCCL gather of the accumulators to rank 0 closes the frame inside the timed region.  Rays are counted on the
 device (one ray = one closest-hit query = one `world.hit` call, reference cpu.rs:48).
@@ -59,9 +59,10 @@ def cpu_baseline(trt, desc, depth, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--backend", default="megakernel", choices=["megakernel", "wavefront"])
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--depth", type=int, default=50)
@@ -98,14 +99,16 @@ def main():
     world, cam = trt.world_from_description(desc)
     scene = world.get_bvh()
     total_spp = 4096
-    renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1)
+    backend = trt.BACKEND_WAVEFRONT if args.backend == "wavefront" else trt.BACKEND_MEGAKERNEL
+    renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1, backend=backend)
+    kernel_name = "trt::wavefront_kernel" if args.backend == "wavefront" else "trt::megakernel"
 
     lay = tiles.band_layout(H, world_size, rank)
     band = dict(band_rows=lay["band_rows"], band_stride=lay["band_stride"], band_offset=lay["band_offset"],
                 rows_local=lay["rows_local"]) if world_size > 1 else {}
     rows_local = lay["rows_local"]
     acc = torch.zeros((rows_local, W, 3), dtype=torch.float32, device=dev)
-    ctr = torch.zeros(8, dtype=torch.int64, device=dev)
+    ctr = torch.zeros(16, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream()
     S = args.spp_per_step
 
@@ -148,7 +151,7 @@ def main():
     roofline = None
     if not args.no_roofline_pass:
         # untimed: the same K launches with the counting kernel variant -> exact algorithmic bytes of those launches
-        sctr = torch.zeros(8, dtype=torch.int64, device=dev)
+        sctr = torch.zeros(16, dtype=torch.int64, device=dev)
         scratch = torch.zeros_like(acc)
         for k in range(args.steps):
             step(args.warmup + k, stats=True, counters=sctr, target=scratch)
@@ -164,9 +167,9 @@ def main():
         if os.path.exists(prof):
             with open(prof) as f:
                 pj = json.load(f)
-            key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}"
+            key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}"
             traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "kernel": "trt::megakernel", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4),
                     "bytes_per_ray": round(algorithmic_bytes(c, 0) / max(c["rays"], 1), 2),
@@ -185,7 +188,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.scene} {W}x{H}, depth {args.depth}, {S} spp per step (of 4096), "
-                                   f"megakernel, reference-order BVH, seed 1",
+                                   f"{args.backend}, reference-order BVH, seed 1",
                        "rays": total_rays, "samples": total_samples, "image_rows_per_gpu": rows_local,
                        "parallelism": f"image bands x{world_size}" if world_size > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,

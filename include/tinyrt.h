@@ -134,6 +134,8 @@ typedef struct {
     uint64_t quad_inside_tests;   /* 0 unless collect_stats */
     uint64_t shades;              /* hits whose material was evaluated; 0 unless collect_stats */
     double kernel_ms;             /* device time of the launch(es), HIP events on the launch stream (host-buffer calls only) */
+    uint64_t wave_trips[4];       /* diagnostics, collect_stats only: per-wave loop trips (bounce rounds, box-test steps,
+                                     leaf phases, ray generations); lane-level counts / (64 x these) = SIMD utilisation */
 } trt_stats;
 
 /* Renderer::render(camera, world) (renderer.rs:37-79), synchronous.  `accum` is a HOST buffer
@@ -142,8 +144,8 @@ typedef struct {
 int trt_render(trt_scene *s, const trt_camera *cam, const trt_render_params *p, float *accum, trt_stats *stats);
 
 /* Same, on buffers already resident in HBM.  `d_accum`: device pointer, rows*width*3 f32.
- * `d_counters`: device pointer to 8 uint64 (zeroed by the caller; layout = trt_stats' first seven
- * fields) or NULL.  `stream`: a hipStream_t (NULL = default stream).  Asynchronous: returns after
+ * `d_counters`: device pointer to 16 uint64 (zeroed by the caller; [0..6] = trt_stats' first seven
+ * fields, [8..11] = wave_trips) or NULL.  `stream`: a hipStream_t (NULL = default stream).  Asynchronous: returns after
  * enqueueing; the caller synchronises the stream. */
 int trt_render_device(trt_scene *s, const trt_camera *cam, const trt_render_params *p, float *d_accum,
                       uint64_t *d_counters, void *stream);

@@ -221,7 +221,7 @@ def test_render_on_device_buffers(trt, orc):
     r = trt.Renderer(6, 1, 8, False, desc["background"])
     dev = torch.device("cuda:0")
     acc = torch.zeros((64, 64, 3), dtype=torch.float32, device=dev)
-    ctr = torch.zeros(8, dtype=torch.int64, device=dev)
+    ctr = torch.zeros(16, dtype=torch.int64, device=dev)
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream, ctr.data_ptr(), sample_begin=0, sample_end=2)

@@ -65,10 +65,12 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("node_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("quad_plane_tests", C.c_uint64), ("quad_inside_tests", C.c_uint64),
-                ("shades", C.c_uint64), ("kernel_ms", C.c_double)]
+                ("shades", C.c_uint64), ("kernel_ms", C.c_double), ("wave_trips", C.c_uint64 * 4)]
 
     def as_dict(self):
-        return {n: getattr(self, n) for n, _ in self._fields_}
+        d = {n: getattr(self, n) for n, _ in self._fields_ if n != "wave_trips"}
+        d["wave_trips"] = list(self.wave_trips)
+        return d
 
 
 # name -> (restype, argtypes); the test-suite checks this table against include/tinyrt.h

@@ -7,6 +7,8 @@
 // compute entry point fails with TRT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <stdlib.h>
+
 #include <mutex>
 #include <new>
 #include <string>
@@ -25,6 +27,8 @@ struct trt_scene {
     SceneHost host;
     std::mutex mu;
     std::unordered_map<int, float4*> device_blob;     // device ordinal -> packed scene in HBM
+    struct Workspace { void* ptr = nullptr; size_t bytes = 0; };
+    std::unordered_map<int, Workspace> wavefront_ws;  // device ordinal -> wavefront path-state planes (grown on demand)
 };
 
 namespace {
@@ -131,7 +135,29 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
         if (!ra.accumulate && bytes) TRT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
         return TRT_OK;
     }
-    if (p->backend == TRT_BACKEND_WAVEFRONT) return fail(TRT_ERR_INVALID_ARG, "wavefront backend is not built into this library version");
+    if (p->backend == TRT_BACKEND_WAVEFRONT) {
+        // path-state workspace: 72 B per pixel slot, cached on the scene handle per device.  One wavefront render at a
+        // time per scene handle and device (the workspace is shared); the megakernel has no such restriction.
+        int dev = 0;
+        TRT_HIP(hipGetDevice(&dev));
+        const size_t need = wavefront_workspace_bytes(cam->width, rows);
+        void* ws = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(s->mu);
+            trt_scene::Workspace& w = s->wavefront_ws[dev];
+            if (w.bytes < need) {
+                if (w.ptr) { TRT_HIP(hipStreamSynchronize(stream)); TRT_HIP(hipFree(w.ptr)); w.ptr = nullptr; w.bytes = 0; }
+                TRT_HIP(hipMalloc(&w.ptr, need));
+                w.bytes = need;
+            }
+            ws = w.ptr;
+        }
+        uint32_t serve_min = 0;
+        if (const char* e = getenv("TRT_WF_SERVE_MIN")) serve_min = (uint32_t)atoi(e);
+        TRT_HIP(launch_wavefront(sc, cd, ra, ws, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0,
+                                 serve_min, stream));
+        return TRT_OK;
+    }
     TRT_HIP(launch_megakernel(sc, cd, ra, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));
     return TRT_OK;
 }
@@ -139,6 +165,7 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
 void counters_to_stats(const unsigned long long* c, trt_stats* st) {
     st->samples = c[CTR_SAMPLES]; st->rays = c[CTR_RAYS]; st->node_tests = c[CTR_NODE]; st->sphere_tests = c[CTR_SPHERE];
     st->quad_plane_tests = c[CTR_QUAD_PLANE]; st->quad_inside_tests = c[CTR_QUAD_INSIDE]; st->shades = c[CTR_SHADE];
+    for (int i = 0; i < 4; i++) st->wave_trips[i] = c[CTR_W_ROUNDS + i];
 }
 
 }  // namespace
@@ -234,6 +261,8 @@ void trt_scene_destroy(trt_scene* s) {
         int prev = 0;
         if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(kv.first) == hipSuccess) {
             (void)hipFree(kv.second);
+            auto ws = s->wavefront_ws.find(kv.first);
+            if (ws != s->wavefront_ws.end() && ws->second.ptr) (void)hipFree(ws->second.ptr);
             (void)hipSetDevice(prev);
         }
     }

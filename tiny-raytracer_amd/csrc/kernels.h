@@ -37,7 +37,9 @@ inline uint32_t rng_seed_key(uint32_t seed) {
 }
 
 // counters[0..6] = samples, rays, node_tests, sphere_tests, quad_plane_tests, quad_inside_tests, shades
-enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_COUNT = 8 };
+// counters[8..11] (collect_stats only) = wave-level loop trips: bounce rounds, box-test steps, leaf phases, ray generations
+enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE,
+       CTR_W_ROUNDS = 8, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_COUNT = 16 };
 
 // Largest packed scene the megakernel copies into LDS (one copy per workgroup).
 constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
@@ -45,6 +47,18 @@ constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
 // Megakernel: whole bounce loop for every pixel of the local rows in one launch.
 hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
                              unsigned long long* d_counters, bool stats, hipStream_t stream);
+
+// Wavefront backend (wavefront.hip): path state lives SoA in a caller-provided HBM workspace.
+struct WfState {
+    float4* s0;     // origin.xyz, hit t
+    float4* s1;     // direction.xyz, bits(hit primitive)
+    float4* s2;     // throughput.xyz, bits(remaining bounces)
+    float4* s3;     // radiance.xyz, bits(sample index)
+    uint2* rng;     // trt-rng v1 stream state
+};
+size_t wavefront_workspace_bytes(uint32_t width, uint32_t rows);
+hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
+                            unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream);
 
 // Sampler plug-in form: n caller-supplied rays.
 hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out,

@@ -1,0 +1,293 @@
+// rt_path.h — device building blocks shared by both backends (megakernel and wavefront): scene
+// access, the reference-order closest-hit traversal, hit shading / scattering, primary rays.
+//
+// What is restated here is the reference's hot path, raytracer/src/renderer/sampler/cpu.rs:39-65
+// and its callees, plus primary-ray generation (renderer/pointgen.rs:37-52, camera.rs:58-66).
+#pragma once
+
+#include "kernels.h"
+#include "rt_device.h"
+
+namespace trt {
+
+extern __shared__ float4 g_lds[];          // dynamic LDS: [scene copy (LDS variants)] [backend-private area]
+
+// ------------------------------------------------------------------------------------------------
+// Scene access: LDS copy or global blob, same element offsets (scene.h).
+// ------------------------------------------------------------------------------------------------
+template <bool LDS>
+struct SceneAcc {
+    const float4* blob;
+    SceneLayout L;
+    TRT_DEV float4 f4(uint32_t idx) const { return LDS ? g_lds[idx] : blob[idx]; }
+    TRT_DEV uint32_t u32(uint32_t idx) const {
+        return LDS ? reinterpret_cast<const uint32_t*>(g_lds)[idx] : reinterpret_cast<const uint32_t*>(blob)[idx];
+    }
+    TRT_DEV float4 node_a(uint32_t i) const { return f4(i); }
+    TRT_DEV float4 node_b(uint32_t i) const { return f4(L.off_node_b + i); }
+    TRT_DEV float4 sphere(uint32_t i) const { return f4(L.off_sphere + i); }
+    TRT_DEV float4 quad(uint32_t plane, uint32_t i) const { return f4(L.off_quad + plane * L.n_quads + i); }
+    TRT_DEV float4 material(uint32_t i) const { return f4(L.off_material + i); }
+    TRT_DEV uint32_t sphere_material(uint32_t i) const { return u32(L.off_sphere_mat + i); }
+    TRT_DEV uint32_t material_kind(uint32_t i) const { return u32(L.off_material_kind + i); }
+};
+
+// Cooperative copy of the packed scene into the front of dynamic LDS (whole workgroup; barrier inside).
+template <bool LDS>
+TRT_DEV void stage_scene_to_lds(const SceneDev& sc) {
+    if constexpr (LDS) {
+        const uint32_t n16 = sc.L.blob_bytes >> 4;
+        for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) g_lds[k] = sc.blob[k];
+        __syncthreads();
+    }
+}
+
+template <bool STATS>
+struct Counters {
+    uint32_t node = 0, sphere = 0, quad_plane = 0, quad_inside = 0, shade = 0;
+    uint32_t w_rounds = 0, w_steps = 0, w_leaf = 0, w_gen = 0;     // wave-level trips, counted by the first active lane
+};
+template <>
+struct Counters<false> {};
+
+TRT_DEV bool first_active_lane() {
+    return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Closest hit: BVH::hit / Node::hit (hittable/bvh.rs:24-27,88-107) with t_range = 0.001..inf
+// (cpu.rs:48).
+//
+// Node::hit tests the box with the interval it was handed; an inner node hands its left child the
+// same interval and its right child [t_min, t_left) if the left child hit.  Walking the pre-order
+// array with one running t_best, used as the exclusive end for boxes and primitives alike, is that
+// recursion unrolled: a primitive is accepted only if t < t_best, so on equal t the primitive that
+// comes first in left-first order wins, as in bvh.rs:96-101.
+// ------------------------------------------------------------------------------------------------
+constexpr float kTMin = 0.001f;
+
+struct Trav {
+    V3 inv;                 // 1/d per axis (aabb.rs:42), hoisted out of the node loop
+    float t_best;
+    uint32_t prim_best;
+    uint32_t i;             // pre-order cursor; i >= n_nodes means the walk is over
+    bool fast;              // slab_fast is exact for this ray (see rt_device.h)
+};
+
+template <bool LDS>
+TRT_DEV Trav trav_begin(const SceneAcc<LDS>& sc, const Ray& ray) {
+    Trav tr;
+    tr.inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
+    tr.fast = sc.L.all_finite && finite_f(tr.inv.x) && finite_f(tr.inv.y) && finite_f(tr.inv.z) && finite_f(ray.o.x) &&
+              finite_f(ray.o.y) && finite_f(ray.o.z);
+    tr.t_best = __builtin_inff();
+    tr.prim_best = PRIM_NONE;
+    tr.i = 0;
+    return tr;
+}
+
+// One box test at the cursor.  Returns the leaf's primitive reference if the cursor stood on a leaf
+// whose box the ray hits (the caller must then run trav_leaf before the next step), else PRIM_NONE.
+template <bool LDS, bool STATS>
+TRT_DEV uint32_t trav_box_step(const SceneAcc<LDS>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
+    float4 na = sc.node_a(tr.i), nb = sc.node_b(tr.i);
+    if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+    bool pass;
+    if (__builtin_expect(tr.fast, 1)) pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
+    else pass = slab_exact(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
+    uint32_t prim = __float_as_uint(nb.w);
+    tr.i = pass ? tr.i + 1u : __float_as_uint(nb.z);
+    return pass ? prim : PRIM_NONE;
+}
+
+// Primitive test with the interval the leaf's box was tested with (bvh.rs:93-94).
+template <bool LDS, bool STATS>
+TRT_DEV void trav_leaf(const SceneAcc<LDS>& sc, const Ray& ray, Trav& tr, uint32_t leaf, Counters<STATS>& ctr) {
+    const uint32_t idx = leaf & PRIM_INDEX_MASK;
+    if (leaf & PRIM_QUAD_BIT) {                                        // Quad::hit, quad.rs:33-54
+        if constexpr (STATS) ctr.quad_plane++;
+        float4 q0 = sc.quad(0, idx);
+        V3 nrm = v3(q0.x, q0.y, q0.z);
+        float dir_norm = dot(ray.d, nrm);
+        float t = (q0.w - dot(ray.o, nrm)) / dir_norm;
+        if (kTMin <= t && t < tr.t_best) {
+            if constexpr (STATS) ctr.quad_inside++;
+            float4 q1 = sc.quad(1, idx), q2 = sc.quad(2, idx), q3 = sc.quad(3, idx), q4 = sc.quad(4, idx);
+            V3 p = ray_at(ray, t) - v3(q1.x, q1.y, q1.z);
+            V3 vv = v3(q2.x, q2.y, q2.z), ww = v3(q2.w, q3.x, q3.y), uu = v3(q3.z, q3.w, q4.x);
+            float planar_x = dot(cross(p, vv), ww);
+            float planar_y = dot(cross(uu, p), ww);
+            if (0.0f <= planar_x && planar_x < 1.0f && 0.0f <= planar_y && planar_y < 1.0f) {
+                tr.t_best = t;
+                tr.prim_best = leaf;
+            }
+        }
+    } else {                                                           // Sphere::hit, sphere.rs:29-54
+        if constexpr (STATS) ctr.sphere++;
+        float t;
+        if (sphere_test(sc.sphere(idx), ray, kTMin, tr.t_best, t)) {
+            tr.t_best = t;
+            tr.prim_best = leaf;
+        }
+    }
+}
+
+// Whole walk for one lane ("while-while": the lanes of a wave run box tests together, then
+// primitive tests together).  Returns the primitive reference (PRIM_NONE on a miss) and its t.
+template <bool LDS, bool STATS>
+TRT_DEV uint32_t closest_hit(const SceneAcc<LDS>& sc, const Ray& ray, float& t_hit, Counters<STATS>& ctr) {
+    Trav tr = trav_begin(sc, ray);
+    const uint32_t n = sc.L.n_nodes;
+    for (;;) {
+        uint32_t leaf = PRIM_NONE;
+        while (tr.i < n) {
+            leaf = trav_box_step<LDS, STATS>(sc, ray, tr, ctr);
+            if (leaf != PRIM_NONE) break;
+        }
+        if (leaf == PRIM_NONE) break;
+        if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+        trav_leaf<LDS, STATS>(sc, ray, tr, leaf, ctr);
+    }
+    t_hit = tr.t_best;
+    return tr.prim_best;
+}
+
+// Material index of a primitive reference.
+template <bool LDS>
+TRT_DEV uint32_t prim_material(const SceneAcc<LDS>& sc, uint32_t prim) {
+    const uint32_t idx = prim & PRIM_INDEX_MASK;
+    return (prim & PRIM_QUAD_BIT) ? __float_as_uint(sc.quad(1, idx).w) : sc.sphere_material(idx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One pass of the loop body of CpuSampler::single_point_sampling after the hit query (cpu.rs:48-62):
+// emission, scatter, attenuation.  Returns true when the path ended (light, miss, budget spent).
+// ------------------------------------------------------------------------------------------------
+struct Path {
+    Ray ray;
+    V3 color, atten;
+    uint32_t remain;
+    Rng rng;
+};
+
+template <bool LDS, bool STATS>
+TRT_DEV bool shade_hit(const SceneAcc<LDS>& sc, Path& p, uint32_t prim, float t, V3 background, Counters<STATS>& ctr) {
+    if (prim == PRIM_NONE) {                                           // cpu.rs:58-61
+        p.color = p.color + p.atten * background;
+        return true;
+    }
+    if constexpr (STATS) ctr.shade++;
+    // HitRecord::new (hittable/mod.rs:28-48), built once for the winning primitive
+    const uint32_t idx = prim & PRIM_INDEX_MASK;
+    V3 point = ray_at(p.ray, t);
+    V3 normal;
+    bool front_face;
+    uint32_t mat;
+    if (prim & PRIM_QUAD_BIT) {
+        float4 q0 = sc.quad(0, idx), q1 = sc.quad(1, idx), q4 = sc.quad(4, idx);
+        front_face = dot(p.ray.d, v3(q0.x, q0.y, q0.z)) < 0.0f;        // outward normal = n, un-normalised (quad.rs:45)
+        V3 nu = v3(q4.y, q4.z, q4.w);                                  // n.normalized(), precomputed on the host
+        normal = front_face ? nu : -nu;
+        mat = __float_as_uint(q1.w);
+    } else {
+        float4 sp = sc.sphere(idx);
+        V3 outward = point - v3(sp.x, sp.y, sp.z);                     // sphere.rs:47-51 (p = ray.at(t))
+        front_face = dot(p.ray.d, outward) < 0.0f;
+        V3 nu = normalized(outward);
+        normal = front_face ? nu : -nu;
+        mat = sc.sphere_material(idx);
+    }
+    const float4 m = sc.material(mat);
+    const uint32_t kind = sc.material_kind(mat);
+    const V3 albedo = v3(m.x, m.y, m.z);
+    // cpu.rs:49-50: emitted() is the light's colour, None -> 0 for everything else (material/mod.rs:8-10)
+    V3 emission = (kind == TRT_LIGHT) ? albedo : v3(0.0f, 0.0f, 0.0f);
+    p.color = p.color + p.atten * emission;
+    V3 dir;
+    if (kind == TRT_LAMBERTIAN) {                                      // lambertian.rs:16-22
+        dir = normal + random_unit_vector(p.rng);
+        if (near_zero(dir)) dir = normal;
+    } else if (kind == TRT_METAL) {                                    // metal.rs:18-25 (fuzz clamped at creation)
+        V3 reflected = reflect(p.ray.d, normal);
+        dir = reflected + m.w * random_in_unit_sphere(p.rng);
+    } else if (kind == TRT_DIELECTRIC) {                               // dielectric.rs:26-46
+        float ri = front_face ? 1.0f / m.w : m.w;
+        float cosv = __builtin_fminf(-dot(normal, p.ray.d), 1.0f);
+        float sinv = __builtin_sqrtf(1.0f - cosv * cosv);
+        bool total_reflection = ri * sinv > 1.0f;
+        float sqrt_r0 = (1.0f - ri) / (1.0f + ri);                     // reflectance(), dielectric.rs:16-22
+        float r0 = sqrt_r0 * sqrt_r0;
+        float x = 1.0f - cosv;
+        float x2 = x * x;
+        float reflectance = r0 + (1.0f - r0) * (x * (x2 * x2));        // powi(5): x * ((x*x)*(x*x))
+        bool do_reflect = total_reflection;
+        if (!do_reflect) do_reflect = reflectance > rng_random(p.rng); // `||` short-circuit: no draw on TIR
+        dir = do_reflect ? reflect(p.ray.d, normal) : refract(p.ray.d, normal, ri);
+    } else {                                                           // Light::scatter -> None (light.rs:17-19)
+        return true;
+    }
+    p.atten = p.atten * albedo;                                        // cpu.rs:52
+    p.ray = ray_new(point, dir);                                       // Ray::new normalises (ray.rs:12-14)
+    p.remain -= 1u;                                                    // cpu.rs:54
+    return p.remain == 0u;
+}
+
+// SamplePointGenerator::generate body (pointgen.rs:41-43) + Camera::get_ray (camera.rs:58-66)
+TRT_DEV Ray primary_ray(const CameraDev& cam, uint32_t x, uint32_t y, Rng& rng) {
+    float u = ((float)x + rng_random(rng)) / (float)(cam.width - 1u);
+    float v = ((float)y + rng_random(rng)) / (float)(cam.height - 1u);
+    float px, py;
+    random_in_unit_disk(rng, px, py);
+    V3 pos = v3(cam.pos[0], cam.pos[1], cam.pos[2]);
+    V3 du = v3(cam.du[0], cam.du[1], cam.du[2]), dv = v3(cam.dv[0], cam.dv[1], cam.dv[2]);
+    V3 origin = (pos + px * du) + py * dv;
+    V3 ul = v3(cam.upper_left[0], cam.upper_left[1], cam.upper_left[2]);
+    V3 hor = v3(cam.horizontal[0], cam.horizontal[1], cam.horizontal[2]);
+    V3 ver = v3(cam.vertical[0], cam.vertical[1], cam.vertical[2]);
+    V3 target = (ul + u * hor) - v * ver;
+    return ray_new(origin, target - origin);
+}
+
+// Start sample `s` of image pixel (x, y): fresh RNG stream, primary ray, colour 0, attenuation 1 (cpu.rs:42-45).
+TRT_DEV void path_begin(Path& p, const CameraDev& cam, const RenderArgs& ra, uint32_t x, uint32_t y, uint32_t s) {
+    p.rng = rng_seed(ra.seed_key, y * cam.width + x, s);
+    p.ray = primary_ray(cam, x, y, p.rng);
+    p.color = v3(0.0f, 0.0f, 0.0f);
+    p.atten = v3(1.0f, 1.0f, 1.0f);
+    p.remain = ra.max_bounces;
+}
+
+// local row -> image row (tinyrt.h trt_render_params)
+TRT_DEV uint32_t image_row(const RenderArgs& ra, uint32_t row) {
+    if (ra.band_rows == 0u) return row;
+    return ((row / ra.band_rows) * ra.band_stride + ra.band_offset) * ra.band_rows + row % ra.band_rows;
+}
+
+TRT_DEV uint32_t wave_sum(uint32_t v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// All 64 lanes must call this (inactive pixels pass zeros).
+template <bool STATS>
+TRT_DEV void flush_counters(unsigned long long* counters, uint32_t samples, uint32_t rays, const Counters<STATS>& ctr) {
+    if (counters == nullptr) return;
+    const bool lane0 = (threadIdx.x & 63u) == 0u;
+    uint32_t s = wave_sum(samples), r = wave_sum(rays);
+    if (lane0) {
+        if (s) atomicAdd(&counters[CTR_SAMPLES], (unsigned long long)s);
+        if (r) atomicAdd(&counters[CTR_RAYS], (unsigned long long)r);
+    }
+    if constexpr (STATS) {
+        uint32_t v[9] = {ctr.node, ctr.sphere, ctr.quad_plane, ctr.quad_inside, ctr.shade, ctr.w_rounds, ctr.w_steps, ctr.w_leaf, ctr.w_gen};
+        const int slot[9] = {CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_W_ROUNDS, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN};
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            uint32_t t = wave_sum(v[k]);
+            if (lane0 && t) atomicAdd(&counters[slot[k]], (unsigned long long)t);
+        }
+    }
+}
+
+}  // namespace trt
