@@ -1,0 +1,167 @@
+// tinyrt.hpp — C++17 host-side mirror of the reference crate's World / Camera / Renderer surface,
+// header-only, over the C ABI in tinyrt.h.
+//
+// The reference is compiled code (Rust); no Rust toolchain exists in the build image, so the host
+// side above the C ABI is C++ and keeps the crate's names, argument order and meaning (paths
+// relative to raytracer/src):
+//
+//   World::add_material / add_geometry / get_material / get_bvh     hittable/world.rs:16-45
+//   Sphere(center, radius, material), Quad(corner, u, v, material)  hittable/sphere.rs:16-26, quad.rs:20-29
+//   Lambertian / Metal / Dielectric / Light                          material/*.rs
+//   Camera(focus_distance, defocus_angle, position, look_at, up, vertical_fov, width, height)  camera.rs:17-26
+//   Renderer(samples_per_pixel, num_sampler_threads, max_bounces, progressbar, background)     renderer/renderer.rs:21-35
+//   Renderer::render(camera, world) -> Image                         renderer/renderer.rs:37-79
+//   Image::get_pixel / save                                          utils/image.rs:46-48,66-69
+//
+// Error behaviour: where the reference panics (duplicate material name world.rs:29-31, failed
+// joins renderer.rs:75-77) this throws tinyrt::Error carrying the C ABI's status and message.
+// A Rust `-sys` binding of the same ABI is sketched in INTEGRATION.md.
+#pragma once
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "tinyrt.h"
+
+namespace tinyrt {
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& what) : std::runtime_error(what), code(c) {}
+};
+inline void check(int rc) {
+    if (rc != TRT_OK) throw Error(rc, std::string("tinyrt error ") + std::to_string(rc) + ": " + trt_last_error());
+}
+
+struct Vec3 : trt_vec3 {
+    Vec3() : trt_vec3{0.0f, 0.0f, 0.0f} {}
+    Vec3(float x_, float y_, float z_) : trt_vec3{x_, y_, z_} {}
+    static Vec3 new_diagonal(float v) { return Vec3(v, v, v); }        // math/vec3.rs:23-25
+    static Vec3 zero() { return Vec3(); }                              // math/vec3.rs:27-29
+};
+
+// ---- materials: values handed to World::add_material (material/*.rs) ----
+struct Material { trt_material pod; };
+inline Material Lambertian(Vec3 albedo) { return Material{{TRT_LAMBERTIAN, albedo, 0.0f}}; }
+inline Material Metal(Vec3 albedo, float fuzz) { return Material{{TRT_METAL, albedo, fuzz}}; }
+inline Material Dielectric(Vec3 albedo, float refraction_index) { return Material{{TRT_DIELECTRIC, albedo, refraction_index}}; }
+inline Material Light(Vec3 color) { return Material{{TRT_LIGHT, color, 0.0f}}; }
+using MaterialHandle = uint32_t;     // stands in for Arc<Box<dyn Material>>
+
+// ---- geometry values handed to World::add_geometry ----
+struct Sphere { Vec3 center; float radius; MaterialHandle material; };
+struct Quad { Vec3 corner, u, v; MaterialHandle material; };
+
+class World {
+public:
+    World() { check(trt_world_create(&w_)); }
+    ~World() { if (scene_) trt_scene_destroy(scene_); trt_world_destroy(w_); }
+    World(const World&) = delete;
+    World& operator=(const World&) = delete;
+
+    void add_material(const std::string& name, const Material& m) { check(trt_world_add_material(w_, name.c_str(), &m.pod)); }
+    std::optional<MaterialHandle> get_material(const std::string& name) const {
+        uint32_t idx = 0;
+        int rc = trt_world_get_material(w_, name.c_str(), &idx);
+        if (rc == TRT_ERR_NOT_FOUND) return std::nullopt;              // world.rs:35-41 returns Option
+        check(rc);
+        return idx;
+    }
+    void add_geometry(const Sphere& s) { invalidate(); check(trt_world_add_sphere(w_, s.center, s.radius, s.material)); }
+    void add_geometry(const Quad& q) { invalidate(); check(trt_world_add_quad(w_, q.corner, q.u, q.v, q.material)); }
+    // new_box(a, b, material) of the reference binary (src/main.rs:89-125): six quads, same push order
+    void add_box(Vec3 a, Vec3 b, MaterialHandle m) {
+        Vec3 mn(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z);
+        Vec3 mx(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z);
+        Vec3 dx(mx.x - mn.x, 0, 0), dy(0, mx.y - mn.y, 0), dz(0, 0, mx.z - mn.z);
+        auto neg = [](Vec3 v) { return Vec3(-v.x, -v.y, -v.z); };
+        add_geometry(Quad{Vec3(mn.x, mn.y, mx.z), dx, dy, m});
+        add_geometry(Quad{Vec3(mx.x, mn.y, mx.z), neg(dz), dy, m});
+        add_geometry(Quad{Vec3(mx.x, mn.y, mn.z), neg(dx), dy, m});
+        add_geometry(Quad{Vec3(mn.x, mn.y, mn.z), dz, dy, m});
+        add_geometry(Quad{Vec3(mn.x, mx.y, mx.z), dx, neg(dz), m});
+        add_geometry(Quad{Vec3(mn.x, mn.y, mn.z), dx, dz, m});
+    }
+    // World::get_bvh (world.rs:43-45): the reference-order BVH, packed for the GPU; cached until the world changes
+    trt_scene* get_bvh() {
+        if (!scene_) check(trt_scene_create(w_, &scene_));
+        return scene_;
+    }
+    int num_geometries() const { return trt_world_num_geometries(w_); }
+
+private:
+    void invalidate() { if (scene_) { trt_scene_destroy(scene_); scene_ = nullptr; } }
+    trt_world* w_ = nullptr;
+    trt_scene* scene_ = nullptr;
+};
+
+class Camera {
+public:
+    Camera(float focus_distance, float defocus_angle, Vec3 position, Vec3 look_at, Vec3 up, float vertical_fov, uint32_t width,
+           uint32_t height) {
+        check(trt_camera_init(&pod, focus_distance, defocus_angle, position, look_at, up, vertical_fov, width, height));
+    }
+    std::pair<uint32_t, uint32_t> get_image_size() const { return {pod.width, pod.height}; }   // camera.rs:68-70
+    trt_camera pod;
+};
+
+// utils/image.rs: Image with gamma 2.2 as the Imager builds it (imager.rs:37-41); holds the linear sums
+class Image {
+public:
+    Image(uint32_t w, uint32_t h, float gamma = 2.2f) : width_(w), height_(h), gamma_(gamma), data_((size_t)w * h * 3, 0.0f) {}
+    uint32_t width() const { return width_; }
+    uint32_t height() const { return height_; }
+    float* linear() { return data_.data(); }
+    const float* linear() const { return data_.data(); }
+    std::vector<uint8_t> to_rgb8() const {
+        std::vector<uint8_t> rgb(data_.size());
+        check(trt_tonemap_u8(data_.data(), width_ * height_, gamma_, rgb.data()));
+        return rgb;
+    }
+    // Image::save writes a PNG through the `image` crate (image.rs:66-69); this mirror writes binary PPM
+    void save(const std::string& filename) const {
+        auto rgb = to_rgb8();
+        FILE* f = std::fopen(filename.c_str(), "wb");
+        if (!f) throw Error(TRT_ERR_INVALID_ARG, "cannot open " + filename);
+        std::fprintf(f, "P6\n%u %u\n255\n", width_, height_);
+        std::fwrite(rgb.data(), 1, rgb.size(), f);
+        std::fclose(f);
+    }
+
+private:
+    uint32_t width_, height_;
+    float gamma_;
+    std::vector<float> data_;
+};
+
+class Renderer {
+public:
+    Renderer(uint32_t samples_per_pixel, uint32_t num_sampler_threads, uint32_t max_bounces, bool progressbar,
+             std::optional<Vec3> background_color, uint32_t seed = 1, uint32_t backend = TRT_BACKEND_MEGAKERNEL) {
+        (void)num_sampler_threads;     // the GPU needs no sampler-task count; kept for signature parity
+        (void)progressbar;
+        params_ = trt_render_params{};
+        params_.samples_per_pixel = samples_per_pixel;
+        params_.max_bounces = max_bounces;
+        params_.background = background_color.value_or(Vec3::zero());  // renderer.rs:33
+        params_.seed = seed;
+        params_.backend = backend;
+    }
+    // Renderer::render (renderer.rs:37-79); synchronous (the reference returns a JoinHandle<Image> to await)
+    Image render(const Camera& camera, World& world, trt_stats* stats = nullptr) const {
+        Image img(camera.pod.width, camera.pod.height);
+        check(trt_render(world.get_bvh(), &camera.pod, &params_, img.linear(), stats));
+        return img;
+    }
+    trt_render_params& params() { return params_; }
+
+private:
+    trt_render_params params_;
+};
+
+}  // namespace tinyrt

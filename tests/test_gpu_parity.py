@@ -256,3 +256,20 @@ def test_full_size_properties_cornell_2048(trt):
     # the frame's mean radiance agrees with a low-resolution render of the same scene (law of large numbers)
     small = trt.Renderer(64, 1, 50, False, desc["background"]).render(*reversed(trt.world_from_description(trt.scenes.cornell(128, 128)))).data
     assert abs(full.mean() / small.mean() - 1.0) < 0.05
+
+
+def test_cpp_mirror_renders_the_same_frame(trt, tmp_path):
+    """examples/cornell.cpp (the reference binary src/main.rs written against include/tinyrt.hpp) produces the same
+    quantised frame as the Python mirror: both are thin callers of one C ABI."""
+    import subprocess
+    from test_host_boundary import _build_cpp_example
+    exe = _build_cpp_example(tmp_path)
+    r = subprocess.run([exe, "72", "56", "5"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    ppm = open(tmp_path / "output.ppm", "rb").read()
+    header = b"P6\n72 56\n255\n"
+    assert ppm.startswith(header)
+    desc = trt.scenes.cornell(72, 56)
+    pw, pcam = trt.world_from_description(desc)
+    img = trt.Renderer(5, 8, 20, True, (0.001, 0.001, 0.001)).render(pcam, pw)
+    assert ppm[len(header):] == img.to_u8().tobytes()

@@ -23,8 +23,8 @@ struct SceneAcc {
     TRT_DEV uint32_t u32(uint32_t idx) const {
         return LDS ? reinterpret_cast<const uint32_t*>(g_lds)[idx] : reinterpret_cast<const uint32_t*>(blob)[idx];
     }
-    TRT_DEV float4 node_a(uint32_t i) const { return f4(i); }
-    TRT_DEV float4 node_b(uint32_t i) const { return f4(L.off_node_b + i); }
+    TRT_DEV float4 node_a(uint32_t i) const { return f4(2u * i); }          // the two halves of a node are adjacent:
+    TRT_DEV float4 node_b(uint32_t i) const { return f4(2u * i + 1u); }     // one 32-byte sector per node visit
     TRT_DEV float4 sphere(uint32_t i) const { return f4(L.off_sphere + i); }
     TRT_DEV float4 quad(uint32_t plane, uint32_t i) const { return f4(L.off_quad + plane * L.n_quads + i); }
     TRT_DEV float4 material(uint32_t i) const { return f4(L.off_material + i); }

@@ -36,8 +36,9 @@ struct World {
 
 // Packed scene.  One contiguous blob of 16-byte elements followed by two u32 arrays; the same
 // offsets address it in HBM and, for small scenes, in its LDS copy.
-//   [node_a: n] (min.x, min.y, min.z, max.x)
-//   [node_b: n] (max.y, max.z, bits(skip), bits(prim))      prim: PRIM_NONE | kind bit | index
+//   [node: 2n]  node i = elements 2i, 2i+1 (32 contiguous bytes: a traversal step touches one 32-byte sector)
+//               2i:   (min.x, min.y, min.z, max.x)
+//               2i+1: (max.y, max.z, bits(skip), bits(prim))    prim: PRIM_NONE | kind bit | index
 //   [sphere: ns] (center.xyz, radius)
 //   [quad plane 0: nq] (n.xyz, d)            Quad::hit stage 1   (quad.rs:34-37)
 //   [quad plane 1: nq] (corner.xyz, bits(material))
@@ -48,7 +49,7 @@ struct World {
 //   [sphere_material: ns] u32   [material_kind: nm] u32
 struct SceneLayout {
     uint32_t n_nodes, n_spheres, n_quads, n_materials;
-    uint32_t off_node_b, off_sphere, off_quad, off_material;      // in 16-byte elements
+    uint32_t off_sphere, off_quad, off_material;                  // in 16-byte elements (nodes start at 0)
     uint32_t off_sphere_mat, off_material_kind;                   // in 4-byte elements from blob start
     uint32_t blob_bytes;
     uint32_t all_finite;        // 1: every coordinate is finite and small enough for the fast slab test

@@ -151,7 +151,6 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     const uint32_t ns = (uint32_t)spheres.size(), nq = (uint32_t)q0.size(), nm = (uint32_t)w.materials.size();
     SceneLayout& L = out.layout;
     L.n_nodes = nn; L.n_spheres = ns; L.n_quads = nq; L.n_materials = nm;
-    L.off_node_b = nn;
     L.off_sphere = 2 * nn;
     L.off_quad = L.off_sphere + ns;
     L.off_material = L.off_quad + 5 * nq;
@@ -175,8 +174,8 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
             const Geometry& geo = w.geometries[(size_t)b.node_prim[i]];
             prim = local_index[(size_t)b.node_prim[i]] | (geo.kind == 1 ? PRIM_QUAD_BIT : 0u);
         }
-        f4[i] = F4{bx.lo.x, bx.lo.y, bx.lo.z, bx.hi.x};
-        f4[L.off_node_b + i] = F4{bx.hi.y, bx.hi.z, bitsf((uint32_t)b.node_skip[i]), bitsf(prim)};
+        f4[2 * (size_t)i] = F4{bx.lo.x, bx.lo.y, bx.lo.z, bx.hi.x};
+        f4[2 * (size_t)i + 1] = F4{bx.hi.y, bx.hi.z, bitsf((uint32_t)b.node_skip[i]), bitsf(prim)};
         float* o = &out.bbox6[6 * (size_t)i];
         o[0] = bx.lo.x; o[1] = bx.lo.y; o[2] = bx.lo.z; o[3] = bx.hi.x; o[4] = bx.hi.y; o[5] = bx.hi.z;
     }
