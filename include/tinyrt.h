@@ -87,12 +87,17 @@ typedef struct {
     uint32_t num_nodes, num_spheres, num_quads, num_materials;
     uint32_t max_depth;           /* BVH depth (root = 1) */
     uint32_t device_bytes;        /* size of the packed scene in HBM */
-    uint32_t lds_bytes;           /* bytes the megakernel stages into LDS (0 = traverses from global memory) */
+    uint32_t lds_bytes;           /* bytes the kernels stage into LDS (0 = traverses from global memory) */
+    uint32_t num_cull_nodes;      /* nodes of the culling tree the kernels walk (same leaves, same order, fewer inner nodes) */
 } trt_scene_info;
 int trt_scene_get_info(const trt_scene *s, trt_scene_info *out);
-/* Pre-order node dump for tests: bbox6[6*i..] = min.xyz,max.xyz; prim[i] = geometry insertion index
- * or -1 for an inner node; skip[i] = pre-order index of the next node once subtree i is done. */
+/* Pre-order node dump of the REFERENCE tree (bvh.rs:42-84, node for node): bbox6[6*i..] = min.xyz,max.xyz;
+ * prim[i] = geometry insertion index or -1 for an inner node; skip[i] = pre-order index of the next node
+ * once subtree i is done. */
 int trt_scene_get_nodes(const trt_scene *s, float *bbox6, int32_t *prim, int32_t *skip, uint32_t cap);
+/* Same dump of the CULLING tree: another hierarchy over the reference tree's leaf sequence (identical leaf boxes
+ * in identical order, inner boxes = exact unions), which gives bit-identical hits with fewer box tests. */
+int trt_scene_get_cull_nodes(const trt_scene *s, float *bbox6, int32_t *prim, int32_t *skip, uint32_t cap);
 
 /* ---- Camera (camera.rs:4-14, 17-56) ---- */
 typedef struct {
@@ -122,7 +127,9 @@ typedef struct {
      *   ((r / band_rows) * band_stride + band_offset) * band_rows + r % band_rows.
      * band_rows==0 means the identity map over all `height` rows. */
     uint32_t band_rows, band_stride, band_offset, rows_local;
-    uint32_t collect_stats;       /* 1: also count node/primitive tests (slower kernel variant) */
+    uint32_t collect_stats;       /* 0: count samples and rays only.  1: counting kernel variant walking the REFERENCE tree:
+                                     node/primitive test counts equal the CPU path's (SURVEY §8d's algorithmic bytes).
+                                     2: counting variant walking the culling tree: the box tests actually performed. */
 } trt_render_params;
 
 typedef struct {

@@ -29,9 +29,21 @@ def render_both(trt, orc, desc, spp, depth, seed=1, nthreads=8, stats=True, **ov
     pw, pcam = trt.world_from_description(desc)
     ow, ocam = orc.world_from_description(desc)
     r = trt.Renderer(spp, 1, depth, False, desc["background"], seed=seed)
-    img = r.render(pcam, pw, collect_stats=stats, **over)
+    img = r.render(pcam, pw, collect_stats=False, **over)          # production kernel: walks the culling tree
+    gst = r.last_stats
     acc, st = orc.render(ow, ocam, spp, depth, desc["background"], seed=seed, nthreads=nthreads)
-    return img.data, r.last_stats, acc, st
+    if stats:
+        # counting kernel on the reference tree: same frame, and its counters are the oracle's
+        counted = r.render(pcam, pw, collect_stats=True, **over)
+        assert_bit_equal(counted.data, img.data, "counting kernel (reference tree) vs production kernel (culling tree)")
+        gst = r.last_stats
+        # counting kernel on the culling tree: identical primitive tests and hits, fewer (or equal) box tests
+        own = r.render(pcam, pw, collect_stats=2, **over)
+        assert_bit_equal(own.data, img.data, "counting kernel on the culling tree")
+        for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
+            assert r.last_stats[k] == gst[k], k
+        assert r.last_stats["node_tests"] <= gst["node_tests"]
+    return img.data, gst, acc, st
 
 
 def test_library_sees_the_gpu(trt):

@@ -11,8 +11,13 @@ WAVEFRONT = 1
 def render_wf(trt, desc, spp, depth, seed=1, stats=True, **over):
     pw, pcam = trt.world_from_description(desc)
     r = trt.Renderer(spp, 1, depth, False, desc["background"], seed=seed, backend=WAVEFRONT)
-    img = r.render(pcam, pw, collect_stats=stats, **over)
-    return img.data, r.last_stats
+    img = r.render(pcam, pw, collect_stats=False, **over)          # production kernel: culling tree
+    gst = r.last_stats
+    if stats:
+        counted = r.render(pcam, pw, collect_stats=True, **over)   # counting kernel: reference tree, oracle's counters
+        assert_bit_equal(counted.data, img.data, "wavefront counting kernel vs production kernel")
+        gst = r.last_stats
+    return img.data, gst
 
 
 def oracle(orc, desc, spp, depth, seed=1):

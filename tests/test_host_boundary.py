@@ -154,3 +154,40 @@ def test_cpp_mirror_compiles_and_fails_loudly_without_gpu(trt, tmp_path):
         pytest.skip("a GPU is present")
     r = subprocess.run([exe, "16", "16", "1"], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 1 and "no HIP device visible" in r.stderr
+
+
+@pytest.mark.parametrize("scene", ["cornell", "random_spheres", "grid3000", "mixed"])
+def test_culling_tree_is_a_hierarchy_over_the_reference_leaf_sequence(trt, scene):
+    """The kernels walk a re-clustered tree.  It gives bit-identical hits because (scene.h): same leaves, same order,
+    every inner box the exact union of the leaf boxes below it.  Those three facts are checked here; the images are
+    checked against the oracle in the GPU tests."""
+    if scene == "mixed":
+        desc = trt.scenes.cornell()
+        desc["materials"].append(("glass", 2, (1.0, 1.0, 1.0), 1.5))
+        desc["geometries"] += [("sphere", (30.0, 70.0, 30.0), 9.0, "glass"), ("sphere", (70.0, 45.0, 60.0), 14.0, "white")]
+    else:
+        desc = {"cornell": lambda: trt.scenes.cornell(), "random_spheres": lambda: trt.scenes.random_spheres(),
+                "grid3000": lambda: trt.scenes.sphere_grid(3000, 64, 36)}[scene]()
+    pw, _ = trt.world_from_description(desc)
+    sc = pw.get_bvh()
+    rb, rp, rs = sc.nodes()
+    cb, cp, cs = sc.cull_nodes()
+    ref_leaves = np.flatnonzero(rp >= 0)
+    cull_leaves = np.flatnonzero(cp >= 0)
+    assert np.array_equal(rp[ref_leaves], cp[cull_leaves])                       # same primitives, same order
+    assert np.array_equal(rb[ref_leaves].view(np.uint32), cb[cull_leaves].view(np.uint32))   # same leaf boxes, bit for bit
+    n = len(cp)
+    assert len(cp) <= len(rp) and (cs > np.arange(n)).all() and cs.max() == n and cs[0] <= n
+    leaf_rank = np.cumsum(cp >= 0) - (cp >= 0)                                   # leaves before node i
+    for i in range(n):
+        if cp[i] >= 0:
+            assert cs[i] == i + 1
+            continue
+        inside = cull_leaves[(cull_leaves > i) & (cull_leaves < cs[i])]
+        assert len(inside) >= 2
+        lo = cb[inside, :3].min(axis=0)
+        hi = cb[inside, 3:].max(axis=0)
+        assert np.array_equal(cb[i, :3], lo) and np.array_equal(cb[i, 3:], hi)   # exact union, no slack and no shortfall
+        # children are complete subtrees: every node strictly inside (i, skip[i]) ends inside
+        assert (cs[i + 1:cs[i]] <= cs[i]).all()
+    assert leaf_rank[-1] + (cp[-1] >= 0) == len(ref_leaves)

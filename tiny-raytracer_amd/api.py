@@ -72,13 +72,20 @@ class Scene:
         check(lib.trt_scene_get_info(self._h, C.byref(out)))
         return {n: getattr(out, n) for n, _ in out._fields_}
 
-    def nodes(self):
-        n = self.info()["num_nodes"]
+    def _dump(self, fn, n):
         bbox = np.zeros((n, 6), np.float32)
         prim = np.zeros(n, np.int32)
         skip = np.zeros(n, np.int32)
-        check(lib.trt_scene_get_nodes(self._h, bbox.ctypes.data, prim.ctypes.data, skip.ctypes.data, n))
+        check(fn(self._h, bbox.ctypes.data, prim.ctypes.data, skip.ctypes.data, n))
         return bbox, prim, skip
+
+    def nodes(self):
+        """The reference tree (bvh.rs:42-84 node for node), pre-order: (bbox[n,6], prim[n], skip[n])."""
+        return self._dump(lib.trt_scene_get_nodes, self.info()["num_nodes"])
+
+    def cull_nodes(self):
+        """The culling tree the kernels walk: same leaves in the same order, re-clustered inner nodes."""
+        return self._dump(lib.trt_scene_get_cull_nodes, self.info()["num_cull_nodes"])
 
 
 class World:

@@ -114,6 +114,7 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
         ra.band_rows = p->band_rows; ra.band_stride = p->band_stride; ra.band_offset = p->band_offset;
     }
     ra.rows_local = rows;
+    ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;
 }
 
@@ -274,19 +275,24 @@ int trt_scene_get_info(const trt_scene* s, trt_scene_info* out) {
     out->num_nodes = L.n_nodes; out->num_spheres = L.n_spheres; out->num_quads = L.n_quads; out->num_materials = L.n_materials;
     out->max_depth = s->host.max_depth;
     out->device_bytes = L.blob_bytes;
-    out->lds_bytes = L.blob_bytes <= kLdsSceneMaxBytes ? L.blob_bytes : 0;
+    out->lds_bytes = L.hot_bytes <= kLdsSceneMaxBytes ? L.hot_bytes : 0;
+    out->num_cull_nodes = L.n_cull_nodes;
+    return TRT_OK;
+}
+static int copy_nodes(const NodeDump& d, float* bbox6, int32_t* prim, int32_t* skip, uint32_t cap) {
+    const uint32_t n = (uint32_t)d.skip.size();
+    if (cap < n) return fail(TRT_ERR_INVALID_ARG, "cap is smaller than the node count");
+    for (size_t k = 0; k < 6 * (size_t)n; k++) bbox6[k] = d.bbox6[k];
+    for (uint32_t i = 0; i < n; i++) { prim[i] = d.prim_geo[i]; skip[i] = d.skip[i]; }
     return TRT_OK;
 }
 int trt_scene_get_nodes(const trt_scene* s, float* bbox6, int32_t* prim, int32_t* skip, uint32_t cap) {
     if (!s || !bbox6 || !prim || !skip) return fail(TRT_ERR_INVALID_ARG, "null argument");
-    uint32_t n = s->host.layout.n_nodes;
-    if (cap < n) return fail(TRT_ERR_INVALID_ARG, "cap is smaller than the node count");
-    for (uint32_t i = 0; i < n; i++) {
-        for (int k = 0; k < 6; k++) bbox6[6 * (size_t)i + k] = s->host.bbox6[6 * (size_t)i + k];
-        prim[i] = s->host.prim_geo[i];
-        skip[i] = s->host.skip[i];
-    }
-    return TRT_OK;
+    return copy_nodes(s->host.reference, bbox6, prim, skip, cap);
+}
+int trt_scene_get_cull_nodes(const trt_scene* s, float* bbox6, int32_t* prim, int32_t* skip, uint32_t cap) {
+    if (!s || !bbox6 || !prim || !skip) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    return copy_nodes(s->host.culling, bbox6, prim, skip, cap);
 }
 
 // ---- Camera ----
@@ -375,6 +381,7 @@ int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_s
     ra.inv_spp = 1.0f;
     ra.max_bounces = max_bounces;
     ra.seed_key = rng_seed_key(seed);
+    ra.ref_tree = 1u;                             // the batch form always counts: walk the reference tree
     trt_sample_point* d_in = nullptr;
     trt_sampled_color* d_out = nullptr;
     unsigned long long* d_ctr = nullptr;

@@ -27,6 +27,7 @@ struct RenderArgs {
     uint32_t accumulate;
     uint32_t band_rows, band_stride, band_offset;   // local row -> image row (tinyrt.h)
     uint32_t rows_local;
+    uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
 };
 
 // trt-rng v1 per-launch key: mix32(seed + golden ratio), evaluated once on the host.
@@ -42,7 +43,7 @@ enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD
        CTR_W_ROUNDS = 8, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_COUNT = 16 };
 
 // Largest packed scene the megakernel copies into LDS (one copy per workgroup).
-constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
+constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;    // compared with SceneLayout::hot_bytes
 
 // Megakernel: whole bounce loop for every pixel of the local rows in one launch.
 hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,

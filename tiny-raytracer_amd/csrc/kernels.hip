@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void megakernel(SceneDev scd, CameraDev cam, R
             }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<LDS, STATS>(sc, p.ray, t, ctr);
+            const uint32_t prim = closest_hit<LDS, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
             if (shade_hit<LDS, STATS>(sc, p, prim, t, background, ctr)) {
                 acc = acc + p.color * ra.inv_spp;                                   // imager.rs:50
                 s++;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SceneDev scd, const t
         if (alive) {
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<LDS, STATS>(sc, p.ray, t, ctr);
+            const uint32_t prim = closest_hit<LDS, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
             if (shade_hit<LDS, STATS>(sc, p, prim, t, background, ctr)) alive = false;
         }
     }
@@ -132,8 +132,8 @@ hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const Ren
     const uint32_t tiles_x = (cam.width + kTile - 1) / kTile, tiles_y = (ra.rows_local + kTile - 1) / kTile;
     if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
     const dim3 grid(tiles_x * tiles_y), block(256);
-    const bool lds = sc.L.blob_bytes <= kLdsSceneMaxBytes;
-    const size_t lds_bytes = lds ? sc.L.blob_bytes : 0;
+    const bool lds = sc.L.hot_bytes <= kLdsSceneMaxBytes;
+    const size_t lds_bytes = lds ? sc.L.hot_bytes : 0;
     if (lds) {
         return stats ? launch(megakernel<true, true>, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x)
                      : launch(megakernel<true, false>, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x);
@@ -146,8 +146,8 @@ hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in,
                                const RenderArgs& ra, unsigned long long* d_counters, bool stats, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const dim3 grid((n + 255u) / 256u), block(256);
-    const bool lds = sc.L.blob_bytes <= kLdsSceneMaxBytes;
-    const size_t lds_bytes = lds ? sc.L.blob_bytes : 0;
+    const bool lds = sc.L.hot_bytes <= kLdsSceneMaxBytes;
+    const size_t lds_bytes = lds ? sc.L.hot_bytes : 0;
     if (lds) {
         return stats ? launch(sample_batch_kernel<true, true>, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters)
                      : launch(sample_batch_kernel<true, false>, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters);

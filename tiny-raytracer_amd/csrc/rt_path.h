@@ -23,8 +23,12 @@ struct SceneAcc {
     TRT_DEV uint32_t u32(uint32_t idx) const {
         return LDS ? reinterpret_cast<const uint32_t*>(g_lds)[idx] : reinterpret_cast<const uint32_t*>(blob)[idx];
     }
-    TRT_DEV float4 node_a(uint32_t i) const { return f4(2u * i); }          // the two halves of a node are adjacent:
-    TRT_DEV float4 node_b(uint32_t i) const { return f4(2u * i + 1u); }     // one 32-byte sector per node visit
+    // culling tree (hot, LDS copy when LDS): the two halves of a node are adjacent, one 32-byte sector per visit
+    TRT_DEV float4 node_a(uint32_t i) const { return f4(2u * i); }
+    TRT_DEV float4 node_b(uint32_t i) const { return f4(2u * i + 1u); }
+    // reference tree: always read from HBM/L2 (counting kernels and NaN-prone rays only)
+    TRT_DEV float4 ref_node_a(uint32_t i) const { return blob[L.off_ref_nodes + 2u * i]; }
+    TRT_DEV float4 ref_node_b(uint32_t i) const { return blob[L.off_ref_nodes + 2u * i + 1u]; }
     TRT_DEV float4 sphere(uint32_t i) const { return f4(L.off_sphere + i); }
     TRT_DEV float4 quad(uint32_t plane, uint32_t i) const { return f4(L.off_quad + plane * L.n_quads + i); }
     TRT_DEV float4 material(uint32_t i) const { return f4(L.off_material + i); }
@@ -36,7 +40,7 @@ struct SceneAcc {
 template <bool LDS>
 TRT_DEV void stage_scene_to_lds(const SceneDev& sc) {
     if constexpr (LDS) {
-        const uint32_t n16 = sc.L.blob_bytes >> 4;
+        const uint32_t n16 = sc.L.hot_bytes >> 4;
         for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) g_lds[k] = sc.blob[k];
         __syncthreads();
     }
@@ -70,16 +74,23 @@ struct Trav {
     V3 inv;                 // 1/d per axis (aabb.rs:42), hoisted out of the node loop
     float t_best;
     uint32_t prim_best;
-    uint32_t i;             // pre-order cursor; i >= n_nodes means the walk is over
+    uint32_t i;             // pre-order cursor
+    uint32_t n;             // node count of the tree this lane walks; i >= n means the walk is over
     bool fast;              // slab_fast is exact for this ray (see rt_device.h)
+    bool ref;               // walk the reference tree instead of the culling tree
 };
 
+// ref_tree: walk the reference tree whatever the ray (counting kernels: their counters then equal the oracle's).
+// A ray whose slab arithmetic can produce NaN (zero / non-finite direction component, non-finite origin) always
+// walks the reference tree with the reference's compare-and-assign slab test.
 template <bool LDS>
-TRT_DEV Trav trav_begin(const SceneAcc<LDS>& sc, const Ray& ray) {
+TRT_DEV Trav trav_begin(const SceneAcc<LDS>& sc, const Ray& ray, bool ref_tree) {
     Trav tr;
     tr.inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     tr.fast = sc.L.all_finite && finite_f(tr.inv.x) && finite_f(tr.inv.y) && finite_f(tr.inv.z) && finite_f(ray.o.x) &&
               finite_f(ray.o.y) && finite_f(ray.o.z);
+    tr.ref = ref_tree || !tr.fast;
+    tr.n = tr.ref ? sc.L.n_nodes : sc.L.n_cull_nodes;
     tr.t_best = __builtin_inff();
     tr.prim_best = PRIM_NONE;
     tr.i = 0;
@@ -90,7 +101,9 @@ TRT_DEV Trav trav_begin(const SceneAcc<LDS>& sc, const Ray& ray) {
 // whose box the ray hits (the caller must then run trav_leaf before the next step), else PRIM_NONE.
 template <bool LDS, bool STATS>
 TRT_DEV uint32_t trav_box_step(const SceneAcc<LDS>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
-    float4 na = sc.node_a(tr.i), nb = sc.node_b(tr.i);
+    float4 na, nb;
+    if (__builtin_expect(tr.ref, 0)) { na = sc.ref_node_a(tr.i); nb = sc.ref_node_b(tr.i); }
+    else { na = sc.node_a(tr.i); nb = sc.node_b(tr.i); }
     if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
     bool pass;
     if (__builtin_expect(tr.fast, 1)) pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
@@ -135,12 +148,11 @@ TRT_DEV void trav_leaf(const SceneAcc<LDS>& sc, const Ray& ray, Trav& tr, uint32
 // Whole walk for one lane ("while-while": the lanes of a wave run box tests together, then
 // primitive tests together).  Returns the primitive reference (PRIM_NONE on a miss) and its t.
 template <bool LDS, bool STATS>
-TRT_DEV uint32_t closest_hit(const SceneAcc<LDS>& sc, const Ray& ray, float& t_hit, Counters<STATS>& ctr) {
-    Trav tr = trav_begin(sc, ray);
-    const uint32_t n = sc.L.n_nodes;
+TRT_DEV uint32_t closest_hit(const SceneAcc<LDS>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr) {
+    Trav tr = trav_begin(sc, ray, ref_tree);
     for (;;) {
         uint32_t leaf = PRIM_NONE;
-        while (tr.i < n) {
+        while (tr.i < tr.n) {
             leaf = trav_box_step<LDS, STATS>(sc, ray, tr, ctr);
             if (leaf != PRIM_NONE) break;
         }

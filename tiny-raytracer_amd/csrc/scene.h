@@ -1,11 +1,23 @@
 // scene.h — host-side scene model and the packed device layout.
 //
 // World mirrors hittable/world.rs:10-45 (insertion-ordered geometry list + name->material map).
-// SceneHost is World::get_bvh() (world.rs:43-45 -> bvh.rs:12-22,42-84) compiled for the GPU:
-// the reference's median-split tree, one primitive per leaf, laid out in PRE-ORDER with a skip
-// link per node.  The reference always descends left first (bvh.rs:96-106), so "next node" is
-// either i+1 (box hit) or skip[i] (box missed / subtree done): a fixed-order traversal needs no
-// stack at all and visits exactly the reference's node sequence.
+// SceneHost is World::get_bvh() (world.rs:43-45 -> bvh.rs:12-22,42-84) compiled for the GPU.
+//
+// Two node arrays are packed, both in PRE-ORDER with a skip link per node.  The reference always
+// descends left first (bvh.rs:96-106), so "next node" is either i+1 (box hit) or skip[i] (box
+// missed / subtree done): a fixed-order traversal needs no stack.
+//
+//  * the REFERENCE tree: the reference's median-split BVH, node for node.  Walking it performs
+//    exactly the reference's box tests; it is what the counting kernels walk (so their counters
+//    equal the CPU oracle's) and what rays take whose slab arithmetic can produce NaN.
+//  * the CULLING tree: another hierarchy over the SAME LEAF SEQUENCE (same leaf boxes, same
+//    order), re-clustered by surface area with near-redundant inner nodes dropped.  It yields
+//    bit-identical hits: inner boxes are exact unions of their leaves' boxes, and for a finite
+//    ray the f32 slab interval of a box contains that of any box inside it (rounding is monotonic),
+//    while t_best only shrinks between an ancestor's test and a descendant's.  So "leaf box
+//    passes" implies "every ancestor passed" in ANY such hierarchy: the set and order of
+//    primitive tests, hence every accepted hit, depend on the leaf sequence alone.  Inner nodes
+//    only decide how much work is skipped.
 #pragma once
 
 #include <stdint.h>
@@ -34,9 +46,9 @@ struct World {
     std::unordered_map<std::string, uint32_t> material_index;   // world.rs:12
 };
 
-// Packed scene.  One contiguous blob of 16-byte elements followed by two u32 arrays; the same
-// offsets address it in HBM and, for small scenes, in its LDS copy.
-//   [node: 2n]  node i = elements 2i, 2i+1 (32 contiguous bytes: a traversal step touches one 32-byte sector)
+// Packed scene: one blob of 16-byte elements.  The first `hot_bytes` are everything a render
+// touches per ray and are what small scenes copy into LDS; the reference tree follows.
+//   [culling nodes: 2m]  node i = elements 2i, 2i+1 (32 contiguous bytes = one sector per visit)
 //               2i:   (min.x, min.y, min.z, max.x)
 //               2i+1: (max.y, max.z, bits(skip), bits(prim))    prim: PRIM_NONE | kind bit | index
 //   [sphere: ns] (center.xyz, radius)
@@ -46,26 +58,33 @@ struct World {
 //   [quad plane 3: nq] (w.y, w.z, u.x, u.y)
 //   [quad plane 4: nq] (u.z, n_unit.xyz)     HitRecord normal    (hittable/mod.rs:35-40)
 //   [material: nm] (albedo.rgb, param)
-//   [sphere_material: ns] u32   [material_kind: nm] u32
+//   [sphere_material: ns] u32   [material_kind: nm] u32          (padded to 16 bytes)   <- hot_bytes end here
+//   [reference nodes: 2n] same node format
 struct SceneLayout {
-    uint32_t n_nodes, n_spheres, n_quads, n_materials;
-    uint32_t off_sphere, off_quad, off_material;                  // in 16-byte elements (nodes start at 0)
+    uint32_t n_nodes;           // reference tree (2N-1)
+    uint32_t n_cull_nodes;      // culling tree
+    uint32_t n_spheres, n_quads, n_materials;
+    uint32_t off_sphere, off_quad, off_material;                  // in 16-byte elements (culling nodes start at 0)
     uint32_t off_sphere_mat, off_material_kind;                   // in 4-byte elements from blob start
-    uint32_t blob_bytes;
+    uint32_t off_ref_nodes;                                       // in 16-byte elements
+    uint32_t hot_bytes, blob_bytes;
     uint32_t all_finite;        // 1: every coordinate is finite and small enough for the fast slab test
+};
+
+struct NodeDump {                            // pre-order inspection copy of one tree
+    std::vector<float> bbox6;
+    std::vector<int32_t> prim_geo;           // geometry insertion index or -1
+    std::vector<int32_t> skip;
 };
 
 struct SceneHost {
     SceneLayout layout;
     std::vector<uint8_t> blob;
     uint32_t max_depth = 0;
-    // test/inspection copies (pre-order)
-    std::vector<float> bbox6;
-    std::vector<int32_t> prim_geo;           // geometry insertion index or -1
-    std::vector<int32_t> skip;
+    NodeDump reference, culling;
 };
 
-// Builds the reference's BVH over `w` and packs it.  Returns false (with msg) on an empty world.
+// Builds the reference's BVH over `w`, derives the culling tree and packs both.  Returns false (with msg) on an empty world.
 bool compile_scene(const World& w, SceneHost& out, std::string& msg);
 
 // Camera::new (camera.rs:17-56)

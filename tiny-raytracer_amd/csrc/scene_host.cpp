@@ -95,6 +95,84 @@ struct Builder {
 inline bool tame(float v) { return fabsf(v) < 1e30f; }
 inline bool tame3(H3 v) { return tame(v.x) && tame(v.y) && tame(v.z); }
 
+inline double surface_area(const Box& b) {
+    double dx = (double)b.hi.x - b.lo.x, dy = (double)b.hi.y - b.lo.y, dz = (double)b.hi.z - b.lo.z;
+    if (!(dx > 0)) dx = 0;
+    if (!(dy > 0)) dy = 0;
+    if (!(dz > 0)) dz = 0;
+    return 2.0 * (dx * dy + dy * dz + dz * dx);
+}
+
+// Culling tree: a second hierarchy over the reference tree's LEAF SEQUENCE (scene.h explains why any such
+// hierarchy gives bit-identical hits).  Contiguous leaf ranges are split where the surface-area heuristic
+// SA(left)*n_left + SA(right)*n_right is smallest; an inner node whose box is at least `kPrune` of its nearest
+// emitted ancestor's is not emitted at all (its children hang directly off that ancestor), since a ray that
+// passed the ancestor almost surely passes it too.  Boxes are exact f32 unions of leaf boxes.
+struct CullBuilder {
+    static constexpr double kPrune = 0.9;
+    const std::vector<Box>& leaf_box;        // leaf k of the reference tree, in left-first order
+    std::vector<Box> node_box;
+    std::vector<int32_t> node_leaf;          // leaf sequence number or -1
+    std::vector<int32_t> node_skip;
+
+    explicit CullBuilder(const std::vector<Box>& lb) : leaf_box(lb) {}
+
+    struct Frame { uint32_t a, b; double parent_sa; int32_t node; bool close; };
+
+    void build() {
+        const uint32_t n = (uint32_t)leaf_box.size();
+        std::vector<Frame> stack;
+        std::vector<Box> suffix;
+        stack.push_back(Frame{0, n, -1.0, -1, false});
+        while (!stack.empty()) {
+            Frame f = stack.back();
+            stack.pop_back();
+            if (f.close) { node_skip[(size_t)f.node] = (int32_t)node_box.size(); continue; }
+            const uint32_t m = f.b - f.a;
+            Box all = leaf_box[f.a];
+            for (uint32_t k = f.a + 1; k < f.b; k++) all = box_union(all, leaf_box[k]);
+            const double sa = surface_area(all);
+            const bool emit = m == 1 || f.parent_sa < 0.0 || sa < kPrune * f.parent_sa;
+            int32_t me = -1;
+            if (emit) {
+                me = (int32_t)node_box.size();
+                node_box.push_back(all);
+                node_leaf.push_back(m == 1 ? (int32_t)f.a : -1);
+                node_skip.push_back(0);
+            }
+            if (m == 1) { node_skip[(size_t)me] = me + 1; continue; }
+            // best split by SAH over the fixed order: prefix boxes on the fly, suffix boxes precomputed
+            suffix.resize(m);
+            suffix[m - 1] = leaf_box[f.b - 1];
+            for (uint32_t k = m - 1; k-- > 0;) suffix[k] = box_union(leaf_box[f.a + k], suffix[k + 1]);
+            Box prefix = leaf_box[f.a];
+            double best = 0.0;
+            uint32_t best_k = 1;
+            for (uint32_t k = 1; k < m; k++) {           // left = [a, a+k), right = [a+k, b)
+                const double c = surface_area(prefix) * k + surface_area(suffix[k]) * (m - k);
+                if (k == 1 || c < best) { best = c; best_k = k; }
+                prefix = box_union(prefix, leaf_box[f.a + k]);
+            }
+            const double child_parent_sa = emit ? sa : f.parent_sa;
+            if (emit) stack.push_back(Frame{0, 0, 0.0, me, true});                         // runs after both subtrees
+            stack.push_back(Frame{f.a + best_k, f.b, child_parent_sa, -1, false});          // right: popped second
+            stack.push_back(Frame{f.a, f.a + best_k, child_parent_sa, -1, false});          // left: popped first
+        }
+    }
+};
+
+void dump_tree(NodeDump& d, const std::vector<Box>& boxes, const std::vector<int32_t>& prim_geo, const std::vector<int32_t>& skip) {
+    const size_t n = boxes.size();
+    d.bbox6.resize(6 * n);
+    d.prim_geo = prim_geo;
+    d.skip = skip;
+    for (size_t i = 0; i < n; i++) {
+        const Box& bx = boxes[i];
+        float* o = &d.bbox6[6 * i];
+        o[0] = bx.lo.x; o[1] = bx.lo.y; o[2] = bx.lo.z; o[3] = bx.hi.x; o[4] = bx.hi.y; o[5] = bx.hi.z;
+    }
+}
+
 }  // namespace
 
 bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
@@ -146,39 +224,56 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     b.node_prim.reserve(2 * ng);
     b.node_skip.reserve(2 * ng);
     b.build(order.data(), ng, 1);
-
     const uint32_t nn = (uint32_t)b.node_box.size();
+
+    // culling tree over the reference tree's leaf sequence
+    std::vector<Box> leaf_box;
+    std::vector<int32_t> leaf_geo;
+    leaf_box.reserve(ng);
+    leaf_geo.reserve(ng);
+    for (uint32_t i = 0; i < nn; i++) {
+        if (b.node_prim[i] >= 0) { leaf_box.push_back(b.node_box[i]); leaf_geo.push_back(b.node_prim[i]); }
+    }
+    CullBuilder cb(leaf_box);
+    cb.build();
+    const uint32_t nc = (uint32_t)cb.node_box.size();
+    std::vector<int32_t> cull_prim_geo(nc);
+    for (uint32_t i = 0; i < nc; i++) cull_prim_geo[i] = cb.node_leaf[i] >= 0 ? leaf_geo[(size_t)cb.node_leaf[i]] : -1;
+
     const uint32_t ns = (uint32_t)spheres.size(), nq = (uint32_t)q0.size(), nm = (uint32_t)w.materials.size();
     SceneLayout& L = out.layout;
-    L.n_nodes = nn; L.n_spheres = ns; L.n_quads = nq; L.n_materials = nm;
-    L.off_sphere = 2 * nn;
+    L.n_nodes = nn; L.n_cull_nodes = nc; L.n_spheres = ns; L.n_quads = nq; L.n_materials = nm;
+    L.off_sphere = 2 * nc;
     L.off_quad = L.off_sphere + ns;
     L.off_material = L.off_quad + 5 * nq;
     uint32_t n_f4 = L.off_material + nm;
     L.off_sphere_mat = n_f4 * 4;
     L.off_material_kind = L.off_sphere_mat + ns;
     uint32_t n_u32 = L.off_material_kind + nm;
-    L.blob_bytes = ((n_u32 * 4u) + 15u) & ~15u;
+    L.hot_bytes = ((n_u32 * 4u) + 15u) & ~15u;
+    L.off_ref_nodes = L.hot_bytes / 16u;
+    L.blob_bytes = L.hot_bytes + 32u * nn;
     L.all_finite = all_finite ? 1u : 0u;
 
     out.blob.assign(L.blob_bytes, 0);
     F4* f4 = reinterpret_cast<F4*>(out.blob.data());
     uint32_t* u32 = reinterpret_cast<uint32_t*>(out.blob.data());
-    out.bbox6.resize(6 * (size_t)nn);
-    out.prim_geo = b.node_prim;
-    out.skip = b.node_skip;
-    for (uint32_t i = 0; i < nn; i++) {
-        const Box& bx = b.node_box[i];
-        uint32_t prim = PRIM_NONE;
-        if (b.node_prim[i] >= 0) {
-            const Geometry& geo = w.geometries[(size_t)b.node_prim[i]];
-            prim = local_index[(size_t)b.node_prim[i]] | (geo.kind == 1 ? PRIM_QUAD_BIT : 0u);
+    auto pack_nodes = [&](F4* dst, const std::vector<Box>& boxes, const std::vector<int32_t>& prim_geo, const std::vector<int32_t>& skip) {
+        for (size_t i = 0; i < boxes.size(); i++) {
+            const Box& bx = boxes[i];
+            uint32_t prim = PRIM_NONE;
+            if (prim_geo[i] >= 0) {
+                const Geometry& geo = w.geometries[(size_t)prim_geo[i]];
+                prim = local_index[(size_t)prim_geo[i]] | (geo.kind == 1 ? PRIM_QUAD_BIT : 0u);
+            }
+            dst[2 * i] = F4{bx.lo.x, bx.lo.y, bx.lo.z, bx.hi.x};
+            dst[2 * i + 1] = F4{bx.hi.y, bx.hi.z, bitsf((uint32_t)skip[i]), bitsf(prim)};
         }
-        f4[2 * (size_t)i] = F4{bx.lo.x, bx.lo.y, bx.lo.z, bx.hi.x};
-        f4[2 * (size_t)i + 1] = F4{bx.hi.y, bx.hi.z, bitsf((uint32_t)b.node_skip[i]), bitsf(prim)};
-        float* o = &out.bbox6[6 * (size_t)i];
-        o[0] = bx.lo.x; o[1] = bx.lo.y; o[2] = bx.lo.z; o[3] = bx.hi.x; o[4] = bx.hi.y; o[5] = bx.hi.z;
-    }
+    };
+    pack_nodes(f4, cb.node_box, cull_prim_geo, cb.node_skip);
+    pack_nodes(f4 + L.off_ref_nodes, b.node_box, b.node_prim, b.node_skip);
+    dump_tree(out.reference, b.node_box, b.node_prim, b.node_skip);
+    dump_tree(out.culling, cb.node_box, cull_prim_geo, cb.node_skip);
     for (uint32_t i = 0; i < ns; i++) { f4[L.off_sphere + i] = spheres[i]; u32[L.off_sphere_mat + i] = sphere_mat[i]; }
     for (uint32_t i = 0; i < nq; i++) {
         f4[L.off_quad + 0 * nq + i] = q0[i];

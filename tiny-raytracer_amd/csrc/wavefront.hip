@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
                                                                uint32_t serve_min) {
     stage_scene_to_lds<LDS>(scd);
     const SceneAcc<LDS> sc{scd.blob, scd.L};
-    WfLds& lds = *reinterpret_cast<WfLds*>(reinterpret_cast<char*>(g_lds) + (LDS ? scd.L.blob_bytes : 0u));
+    WfLds& lds = *reinterpret_cast<WfLds*>(reinterpret_cast<char*>(g_lds) + (LDS ? scd.L.hot_bytes : 0u));
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     WfTile tile;
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
     tile.row0 = (blockIdx.x / tiles_x) * kWfTileH;
     tile.slot0 = (unsigned long long)blockIdx.x * kWfSlots;
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
-    const uint32_t n_nodes = sc.L.n_nodes;
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
 
@@ -134,6 +133,7 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
             Ray ray;
             Trav tr;
             tr.i = 0;
+            tr.n = 0;
             bool exhausted = false;
             for (;;) {
                 if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
                         const float4 a = st.s0[tile.slot0 + slot], d = st.s1[tile.slot0 + slot];
                         ray.o = v3(a.x, a.y, a.z);
                         ray.d = v3(d.x, d.y, d.z);
-                        tr = trav_begin(sc, ray);
+                        tr = trav_begin(sc, ray, ra.ref_tree != 0u);
                         leaf = PRIM_NONE;
                     }
                     exhausted = b + n_free >= n;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
                 if (n_free == 64u) break;                    // nothing in flight and nothing left to pull
                 // box tests while enough lanes take part; lanes on a leaf or at the end of their walk wait
                 for (;;) {
-                    const bool in_box = slot != kNone && leaf == PRIM_NONE && tr.i < n_nodes;
+                    const bool in_box = slot != kNone && leaf == PRIM_NONE && tr.i < tr.n;
                     const uint32_t n_box = popc64(__builtin_amdgcn_ballot_w64(in_box));
                     const uint32_t n_wait = 64u - n_free - n_box;
                     if (n_box == 0u || n_wait >= serve_min) break;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
                     leaf = PRIM_NONE;
                 }
                 // retire finished walks: hit record to HBM, outcome bin to LDS
-                if (slot != kNone && tr.i >= n_nodes) {
+                if (slot != kNone && tr.i >= tr.n) {
                     const unsigned long long g = tile.slot0 + slot;
                     reinterpret_cast<float*>(&st.s0[g])[3] = tr.t_best;
                     reinterpret_cast<uint32_t*>(&st.s1[g])[3] = tr.prim_best;
@@ -286,8 +286,8 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
     st.s2 = st.s1 + n_slots;
     st.s3 = st.s2 + n_slots;
     st.rng = reinterpret_cast<uint2*>(st.s3 + n_slots);
-    const bool lds = sc.L.blob_bytes <= kLdsSceneMaxBytes;
-    const size_t lds_bytes = (lds ? sc.L.blob_bytes : 0) + sizeof(WfLds);
+    const bool lds = sc.L.hot_bytes <= kLdsSceneMaxBytes;
+    const size_t lds_bytes = (lds ? sc.L.hot_bytes : 0) + sizeof(WfLds);
     const dim3 grid(tiles_x * tiles_y), block(kWfThreads);
     if (serve_min == 0) serve_min = 24;
     auto go = [&](auto kernel) -> hipError_t {
