@@ -7,7 +7,7 @@ kernel's algorithmic-byte rate against the HBM roofline and the CPU oracle timed
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of --spp-per-step samples per pixel over the whole image, continuing the running f32 sums that
-stay resident in HBM (the full config's 4096 spp is 64 such steps of 64).  With N > 1 the image's 16-row bands are
+stay resident in HBM (the full config's 4096 spp is 16 such steps of 256).  With N > 1 the image's 16-row bands are
 dealt round-robin to the ranks (strong scaling: the image is fixed), every rank runs the same steps on its rows, and
 one RCCL gather of the accumulators to rank 0 closes the frame inside the timed region.  Rays are counted on the
 device (one ray = one closest-hit query = one `world.hit` call, reference cpu.rs:48).
@@ -59,9 +59,9 @@ def cpu_baseline(trt, desc, depth, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp-per-step", type=int, default=64)
+    ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--backend", default="megakernel", choices=["megakernel", "wavefront"])
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)

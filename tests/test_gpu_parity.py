@@ -103,14 +103,30 @@ def test_random_spheres_lds_resident_scene(trt, orc):
 
 
 def test_large_scene_traversed_from_global_memory(trt, orc):
-    """BASELINE config 5's generator at 4000 spheres: too big for LDS, nodes come through L1/L2."""
+    """BASELINE config 5's generator at 4000 spheres: too big for LDS, everything comes through L1/L2."""
     desc = trt.scenes.sphere_grid(4000, 160, 90)
     pw, _ = trt.world_from_description(desc)
-    assert pw.get_bvh().info()["lds_bytes"] == 0
+    info = pw.get_bvh().info()
+    assert info["device_bytes"] > 64 * 1024 and info["lds_bytes"] == 0
     gpu, gst, cpu, cst = render_both(trt, orc, desc, 4, 50)
     assert_bit_equal(gpu, cpu, "sphere grid 4000")
     for k in STAT_KEYS:
         assert gst[k] == cst[k], k
+
+
+def test_large_scene_with_top_levels_cached_in_lds(trt, orc, monkeypatch):
+    """Optional placement (env TRT_TOP_NODES): the culling tree's top levels first, copied into LDS; same bits."""
+    monkeypatch.setenv("TRT_TOP_NODES", "255")
+    desc = trt.scenes.sphere_grid(4000, 96, 54)
+    pw, _ = trt.world_from_description(desc)
+    info = pw.get_bvh().info()
+    assert 0 < info["lds_bytes"] <= 255 * 32
+    for backend in (0, 1):
+        pw, pcam = trt.world_from_description(desc)
+        gpu = trt.Renderer(4, 1, 50, False, desc["background"], backend=backend).render(pcam, pw).data
+        ow, ocam = orc.world_from_description(desc)
+        cpu, _ = orc.render(ow, ocam, 4, 50, desc["background"], nthreads=8)
+        assert_bit_equal(gpu, cpu, f"hybrid LDS top cache, backend {backend}")
 
 
 @pytest.mark.parametrize("wh", [(2, 2), (17, 5), (33, 47), (64, 16), (130, 3)])

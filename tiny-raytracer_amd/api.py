@@ -194,7 +194,7 @@ class Renderer:
         """Renderer::render: returns the finished Image (the reference returns a JoinHandle<Image>).
         `accum` continues earlier passes when over["accumulate"] is set."""
         scene = world.get_bvh() if isinstance(world, World) else world
-        p = self.params(collect_stats=1 if collect_stats else 0, **over)
+        p = self.params(collect_stats=int(collect_stats), **over)      # 0 | 1 (reference tree) | 2 (culling tree)
         w, h = camera.get_image_size()
         rows = p.rows_local if p.band_rows else h
         if accum is None:

@@ -114,6 +114,7 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
         ra.band_rows = p->band_rows; ra.band_stride = p->band_stride; ra.band_offset = p->band_offset;
     }
     ra.rows_local = rows;
+    ra.xcd_aware = getenv("TRT_XCD_REMAP") ? 1u : 0u;   // off: contiguous image regions per XCD measured 2x slower (load imbalance)
     ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;
 }
@@ -275,7 +276,7 @@ int trt_scene_get_info(const trt_scene* s, trt_scene_info* out) {
     out->num_nodes = L.n_nodes; out->num_spheres = L.n_spheres; out->num_quads = L.n_quads; out->num_materials = L.n_materials;
     out->max_depth = s->host.max_depth;
     out->device_bytes = L.blob_bytes;
-    out->lds_bytes = L.hot_bytes <= kLdsSceneMaxBytes ? L.hot_bytes : 0;
+    out->lds_bytes = scene_lds_bytes(L);
     out->num_cull_nodes = L.n_cull_nodes;
     return TRT_OK;
 }

@@ -27,6 +27,7 @@ struct RenderArgs {
     uint32_t accumulate;
     uint32_t band_rows, band_stride, band_offset;   // local row -> image row (tinyrt.h)
     uint32_t rows_local;
+    uint32_t xcd_aware;          // 1: remap workgroups so that each XCD renders a contiguous image region
     uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
 };
 
@@ -42,8 +43,11 @@ inline uint32_t rng_seed_key(uint32_t seed) {
 enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE,
        CTR_W_ROUNDS = 8, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_COUNT = 16 };
 
-// Largest packed scene the megakernel copies into LDS (one copy per workgroup).
-constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;    // compared with SceneLayout::hot_bytes
+// Largest hot blob (SceneLayout::hot_bytes) copied whole into LDS, once per workgroup; larger scenes keep only
+// the culling tree's top levels there.
+constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
+inline int scene_mode(const SceneLayout& L) { return L.hot_bytes <= kLdsSceneMaxBytes ? 1 : (L.n_top_nodes > 0 ? 2 : 0); }
+inline uint32_t scene_lds_bytes(const SceneLayout& L) { int m = scene_mode(L); return m == 1 ? L.hot_bytes : (m == 2 ? 32u * L.n_top_nodes : 0u); }
 
 // Megakernel: whole bounce loop for every pixel of the local rows in one launch.
 hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,

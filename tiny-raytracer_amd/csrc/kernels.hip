@@ -11,6 +11,8 @@
 //    [t_min, t_best) interval exactly (rt_path.h);
 //  * scenes up to kLdsSceneMaxBytes are copied into LDS once per workgroup and traversed from
 //    there (ds_read_b128 per 16-byte plane element); larger ones are read through L1/L2.
+#include <stdlib.h>
+
 #include "kernels.h"
 #include "rt_path.h"
 
@@ -23,14 +25,15 @@ namespace trt {
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kTile = 16;
 
-template <bool LDS, bool STATS>
-__global__ __launch_bounds__(256) void megakernel(SceneDev scd, CameraDev cam, RenderArgs ra, float* __restrict__ accum,
+template <int MODE, bool STATS, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void megakernel(SceneDev scd, CameraDev cam, RenderArgs ra, float* __restrict__ accum,
                                                   unsigned long long* __restrict__ counters, uint32_t tiles_x) {
-    stage_scene_to_lds<LDS>(scd);
-    const SceneAcc<LDS> sc{scd.blob, scd.L};
+    stage_scene_to_lds<MODE>(scd);
+    const SceneAcc<MODE> sc{scd.blob, scd.L};
 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
-    const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x, ra.xcd_aware);
+    const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint32_t x = tile_x * kTile + (wave & 1u) * 8u + (lane & 7u);
     const uint32_t row = tile_y * kTile + (wave >> 1) * 8u + (lane >> 3);          // local row
     const bool in_image = x < cam.width && row < ra.rows_local;
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256) void megakernel(SceneDev scd, CameraDev cam, R
             }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<LDS, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
-            if (shade_hit<LDS, STATS>(sc, p, prim, t, background, ctr)) {
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
+            if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 acc = acc + p.color * ra.inv_spp;                                   // imager.rs:50
                 s++;
                 fresh = true;
@@ -76,12 +79,12 @@ __global__ __launch_bounds__(256) void megakernel(SceneDev scd, CameraDev cam, R
 // ------------------------------------------------------------------------------------------------
 // Sampler plug-in form (sampler/mod.rs:10-17): one lane per caller-supplied SamplePoint.
 // ------------------------------------------------------------------------------------------------
-template <bool LDS, bool STATS>
+template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void sample_batch_kernel(SceneDev scd, const trt_sample_point* __restrict__ in, uint32_t n,
                                                            trt_sampled_color* __restrict__ out, RenderArgs ra,
                                                            unsigned long long* __restrict__ counters) {
-    stage_scene_to_lds<LDS>(scd);
-    const SceneAcc<LDS> sc{scd.blob, scd.L};
+    stage_scene_to_lds<MODE>(scd);
+    const SceneAcc<MODE> sc{scd.blob, scd.L};
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
     uint32_t n_rays = 0;
@@ -101,8 +104,8 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SceneDev scd, const t
         if (alive) {
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<LDS, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
-            if (shade_hit<LDS, STATS>(sc, p, prim, t, background, ctr)) alive = false;
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
+            if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) alive = false;
         }
     }
     if (i < n) {
@@ -132,28 +135,28 @@ hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const Ren
     const uint32_t tiles_x = (cam.width + kTile - 1) / kTile, tiles_y = (ra.rows_local + kTile - 1) / kTile;
     if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
     const dim3 grid(tiles_x * tiles_y), block(256);
-    const bool lds = sc.L.hot_bytes <= kLdsSceneMaxBytes;
-    const size_t lds_bytes = lds ? sc.L.hot_bytes : 0;
-    if (lds) {
-        return stats ? launch(megakernel<true, true>, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x)
-                     : launch(megakernel<true, false>, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x);
+    const size_t lds_bytes = scene_lds_bytes(sc.L);
+    auto go = [&](auto kernel) { return launch(kernel, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x); };
+    switch (scene_mode(sc.L)) {
+        case MODE_LDS: return stats ? go(megakernel<MODE_LDS, true>) : go(megakernel<MODE_LDS, false>);
+        case MODE_HYBRID: return stats ? go(megakernel<MODE_HYBRID, true>) : go(megakernel<MODE_HYBRID, false>);
+        default:
+            if (getenv("TRT_MINW8")) return stats ? go(megakernel<MODE_GLOBAL, true, 8>) : go(megakernel<MODE_GLOBAL, false, 8>);
+            return stats ? go(megakernel<MODE_GLOBAL, true>) : go(megakernel<MODE_GLOBAL, false>);
     }
-    return stats ? launch(megakernel<false, true>, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x)
-                 : launch(megakernel<false, false>, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x);
 }
 
 hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out,
                                const RenderArgs& ra, unsigned long long* d_counters, bool stats, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     const dim3 grid((n + 255u) / 256u), block(256);
-    const bool lds = sc.L.hot_bytes <= kLdsSceneMaxBytes;
-    const size_t lds_bytes = lds ? sc.L.hot_bytes : 0;
-    if (lds) {
-        return stats ? launch(sample_batch_kernel<true, true>, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters)
-                     : launch(sample_batch_kernel<true, false>, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters);
+    const size_t lds_bytes = scene_lds_bytes(sc.L);
+    auto go = [&](auto kernel) { return launch(kernel, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters); };
+    switch (scene_mode(sc.L)) {
+        case MODE_LDS: return stats ? go(sample_batch_kernel<MODE_LDS, true>) : go(sample_batch_kernel<MODE_LDS, false>);
+        case MODE_HYBRID: return stats ? go(sample_batch_kernel<MODE_HYBRID, true>) : go(sample_batch_kernel<MODE_HYBRID, false>);
+        default: return stats ? go(sample_batch_kernel<MODE_GLOBAL, true>) : go(sample_batch_kernel<MODE_GLOBAL, false>);
     }
-    return stats ? launch(sample_batch_kernel<false, true>, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters)
-                 : launch(sample_batch_kernel<false, false>, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters);
 }
 
 }  // namespace trt

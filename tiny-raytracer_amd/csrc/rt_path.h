@@ -15,32 +15,43 @@ extern __shared__ float4 g_lds[];          // dynamic LDS: [scene copy (LDS vari
 // ------------------------------------------------------------------------------------------------
 // Scene access: LDS copy or global blob, same element offsets (scene.h).
 // ------------------------------------------------------------------------------------------------
-template <bool LDS>
+enum { MODE_GLOBAL = 0,      // scene read through L1/L2
+       MODE_LDS = 1,         // the whole hot part of the blob (culling tree, primitives, materials) copied into LDS
+       MODE_HYBRID = 2 };    // only the culling tree's top levels (its first n_top_nodes nodes) copied into LDS
+
+template <int MODE>
 struct SceneAcc {
     const float4* blob;
     SceneLayout L;
-    TRT_DEV float4 f4(uint32_t idx) const { return LDS ? g_lds[idx] : blob[idx]; }
+    TRT_DEV float4 f4(uint32_t idx) const { return MODE == MODE_LDS ? g_lds[idx] : blob[idx]; }
     TRT_DEV uint32_t u32(uint32_t idx) const {
-        return LDS ? reinterpret_cast<const uint32_t*>(g_lds)[idx] : reinterpret_cast<const uint32_t*>(blob)[idx];
+        return MODE == MODE_LDS ? reinterpret_cast<const uint32_t*>(g_lds)[idx] : reinterpret_cast<const uint32_t*>(blob)[idx];
     }
-    // culling tree (hot, LDS copy when LDS): the two halves of a node are adjacent, one 32-byte sector per visit
-    TRT_DEV float4 node_a(uint32_t i) const { return f4(2u * i); }
-    TRT_DEV float4 node_b(uint32_t i) const { return f4(2u * i + 1u); }
+    // culling tree: the two halves of a node are adjacent (one 32-byte sector per visit)
+    TRT_DEV void node(uint32_t i, float4& a, float4& b) const {
+        if constexpr (MODE == MODE_HYBRID) {
+            if (i < L.n_top_nodes) { a = g_lds[2u * i]; b = g_lds[2u * i + 1u]; }
+            else { a = blob[2u * i]; b = blob[2u * i + 1u]; }
+        } else {
+            a = f4(2u * i); b = f4(2u * i + 1u);
+        }
+    }
     // reference tree: always read from HBM/L2 (counting kernels and NaN-prone rays only)
-    TRT_DEV float4 ref_node_a(uint32_t i) const { return blob[L.off_ref_nodes + 2u * i]; }
-    TRT_DEV float4 ref_node_b(uint32_t i) const { return blob[L.off_ref_nodes + 2u * i + 1u]; }
+    TRT_DEV void ref_node(uint32_t i, float4& a, float4& b) const { a = blob[L.off_ref_nodes + 2u * i]; b = blob[L.off_ref_nodes + 2u * i + 1u]; }
     TRT_DEV float4 sphere(uint32_t i) const { return f4(L.off_sphere + i); }
     TRT_DEV float4 quad(uint32_t plane, uint32_t i) const { return f4(L.off_quad + plane * L.n_quads + i); }
     TRT_DEV float4 material(uint32_t i) const { return f4(L.off_material + i); }
     TRT_DEV uint32_t sphere_material(uint32_t i) const { return u32(L.off_sphere_mat + i); }
     TRT_DEV uint32_t material_kind(uint32_t i) const { return u32(L.off_material_kind + i); }
+    // bytes of dynamic LDS the scene copy occupies (the backend-private area starts there)
+    TRT_DEV uint32_t lds_bytes() const { return MODE == MODE_LDS ? L.hot_bytes : (MODE == MODE_HYBRID ? 32u * L.n_top_nodes : 0u); }
 };
 
-// Cooperative copy of the packed scene into the front of dynamic LDS (whole workgroup; barrier inside).
-template <bool LDS>
+// Cooperative copy into the front of dynamic LDS (whole workgroup; barrier inside).
+template <int MODE>
 TRT_DEV void stage_scene_to_lds(const SceneDev& sc) {
-    if constexpr (LDS) {
-        const uint32_t n16 = sc.L.hot_bytes >> 4;
+    if constexpr (MODE != MODE_GLOBAL) {
+        const uint32_t n16 = (MODE == MODE_LDS ? sc.L.hot_bytes : 32u * sc.L.n_top_nodes) >> 4;
         for (uint32_t k = threadIdx.x; k < n16; k += blockDim.x) g_lds[k] = sc.blob[k];
         __syncthreads();
     }
@@ -83,8 +94,8 @@ struct Trav {
 // ref_tree: walk the reference tree whatever the ray (counting kernels: their counters then equal the oracle's).
 // A ray whose slab arithmetic can produce NaN (zero / non-finite direction component, non-finite origin) always
 // walks the reference tree with the reference's compare-and-assign slab test.
-template <bool LDS>
-TRT_DEV Trav trav_begin(const SceneAcc<LDS>& sc, const Ray& ray, bool ref_tree) {
+template <int MODE>
+TRT_DEV Trav trav_begin(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree) {
     Trav tr;
     tr.inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);
     tr.fast = sc.L.all_finite && finite_f(tr.inv.x) && finite_f(tr.inv.y) && finite_f(tr.inv.z) && finite_f(ray.o.x) &&
@@ -99,23 +110,24 @@ TRT_DEV Trav trav_begin(const SceneAcc<LDS>& sc, const Ray& ray, bool ref_tree) 
 
 // One box test at the cursor.  Returns the leaf's primitive reference if the cursor stood on a leaf
 // whose box the ray hits (the caller must then run trav_leaf before the next step), else PRIM_NONE.
-template <bool LDS, bool STATS>
-TRT_DEV uint32_t trav_box_step(const SceneAcc<LDS>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
+template <int MODE, bool STATS>
+TRT_DEV uint32_t trav_box_step(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
     float4 na, nb;
-    if (__builtin_expect(tr.ref, 0)) { na = sc.ref_node_a(tr.i); nb = sc.ref_node_b(tr.i); }
-    else { na = sc.node_a(tr.i); nb = sc.node_b(tr.i); }
+    if (__builtin_expect(tr.ref, 0)) sc.ref_node(tr.i, na, nb);
+    else sc.node(tr.i, na, nb);
     if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
     bool pass;
     if (__builtin_expect(tr.fast, 1)) pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
     else pass = slab_exact(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
-    uint32_t prim = __float_as_uint(nb.w);
-    tr.i = pass ? tr.i + 1u : __float_as_uint(nb.z);
-    return pass ? prim : PRIM_NONE;
+    const uint32_t link = __float_as_uint(nb.w);
+    const bool inner = (link & NODE_INNER_BIT) != 0u;
+    tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);     // descend, or skip (a leaf's skip is its successor)
+    return (pass && !inner) ? link : PRIM_NONE;
 }
 
 // Primitive test with the interval the leaf's box was tested with (bvh.rs:93-94).
-template <bool LDS, bool STATS>
-TRT_DEV void trav_leaf(const SceneAcc<LDS>& sc, const Ray& ray, Trav& tr, uint32_t leaf, Counters<STATS>& ctr) {
+template <int MODE, bool STATS>
+TRT_DEV void trav_leaf(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, uint32_t leaf, Counters<STATS>& ctr) {
     const uint32_t idx = leaf & PRIM_INDEX_MASK;
     if (leaf & PRIM_QUAD_BIT) {                                        // Quad::hit, quad.rs:33-54
         if constexpr (STATS) ctr.quad_plane++;
@@ -147,26 +159,48 @@ TRT_DEV void trav_leaf(const SceneAcc<LDS>& sc, const Ray& ray, Trav& tr, uint32
 
 // Whole walk for one lane ("while-while": the lanes of a wave run box tests together, then
 // primitive tests together).  Returns the primitive reference (PRIM_NONE on a miss) and its t.
-template <bool LDS, bool STATS>
-TRT_DEV uint32_t closest_hit(const SceneAcc<LDS>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr) {
+// The common case (finite ray, culling tree, min/max slab test) gets a loop of its own so that
+// the rare cases' branches and loads stay out of the hot loop.
+template <int MODE, bool STATS>
+TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr) {
     Trav tr = trav_begin(sc, ray, ref_tree);
-    for (;;) {
-        uint32_t leaf = PRIM_NONE;
-        while (tr.i < tr.n) {
-            leaf = trav_box_step<LDS, STATS>(sc, ray, tr, ctr);
-            if (leaf != PRIM_NONE) break;
+    if (__builtin_expect(!tr.ref, 1)) {
+        const uint32_t n = sc.L.n_cull_nodes;
+        for (;;) {
+            uint32_t leaf = PRIM_NONE;
+            while (tr.i < n) {
+                float4 na, nb;
+                sc.node(tr.i, na, nb);
+                if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+                const bool pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
+                const uint32_t link = __float_as_uint(nb.w);
+                const bool inner = (link & NODE_INNER_BIT) != 0u;
+                tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);
+                if (pass && !inner) { leaf = link; break; }
+            }
+            if (leaf == PRIM_NONE) break;
+            if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+            trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr);
         }
-        if (leaf == PRIM_NONE) break;
-        if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-        trav_leaf<LDS, STATS>(sc, ray, tr, leaf, ctr);
+    } else {
+        for (;;) {
+            uint32_t leaf = PRIM_NONE;
+            while (tr.i < tr.n) {
+                leaf = trav_box_step<MODE, STATS>(sc, ray, tr, ctr);
+                if (leaf != PRIM_NONE) break;
+            }
+            if (leaf == PRIM_NONE) break;
+            if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+            trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr);
+        }
     }
     t_hit = tr.t_best;
     return tr.prim_best;
 }
 
 // Material index of a primitive reference.
-template <bool LDS>
-TRT_DEV uint32_t prim_material(const SceneAcc<LDS>& sc, uint32_t prim) {
+template <int MODE>
+TRT_DEV uint32_t prim_material(const SceneAcc<MODE>& sc, uint32_t prim) {
     const uint32_t idx = prim & PRIM_INDEX_MASK;
     return (prim & PRIM_QUAD_BIT) ? __float_as_uint(sc.quad(1, idx).w) : sc.sphere_material(idx);
 }
@@ -182,8 +216,8 @@ struct Path {
     Rng rng;
 };
 
-template <bool LDS, bool STATS>
-TRT_DEV bool shade_hit(const SceneAcc<LDS>& sc, Path& p, uint32_t prim, float t, V3 background, Counters<STATS>& ctr) {
+template <int MODE, bool STATS>
+TRT_DEV bool shade_hit(const SceneAcc<MODE>& sc, Path& p, uint32_t prim, float t, V3 background, Counters<STATS>& ctr) {
     if (prim == PRIM_NONE) {                                           // cpu.rs:58-61
         p.color = p.color + p.atten * background;
         return true;
@@ -267,6 +301,17 @@ TRT_DEV void path_begin(Path& p, const CameraDev& cam, const RenderArgs& ra, uin
     p.color = v3(0.0f, 0.0f, 0.0f);
     p.atten = v3(1.0f, 1.0f, 1.0f);
     p.remain = ra.max_bounces;
+}
+
+// Workgroup -> tile index.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, each XCD
+// has its own L2).  With xcd_aware, XCD k renders the k-th contiguous eighth of the tiles, which keeps the part of
+// a large scene that an image region touches in one L2.  Placement only: any mapping gives the same frame.
+// Measured on MI355X (100 k spheres, 3840x2160): 2x SLOWER, because image regions differ in cost and whole XCDs
+// go idle; the round-robin default interleaves cheap and expensive tiles on every XCD.  Kept behind TRT_XCD_REMAP.
+TRT_DEV uint32_t xcd_tile(uint32_t block, uint32_t n_blocks, uint32_t xcd_aware) {
+    if (!xcd_aware) return block;
+    const uint32_t per = n_blocks >> 3, main = per << 3;     // the first `main` blocks split evenly; the tail maps to itself
+    return block < main ? (block & 7u) * per + (block >> 3) : block;
 }
 
 // local row -> image row (tinyrt.h trt_render_params)

@@ -32,7 +32,11 @@ namespace trt {
 
 struct F4 { float x, y, z, w; };            // 16-byte plane element (float4 on the device)
 
-enum : uint32_t { PRIM_NONE = 0xFFFFFFFFu, PRIM_QUAD_BIT = 0x40000000u, PRIM_INDEX_MASK = 0x3FFFFFFFu };
+enum : uint32_t { PRIM_NONE = 0xFFFFFFFFu, PRIM_QUAD_BIT = 0x40000000u, PRIM_INDEX_MASK = 0x3FFFFFFFu,
+                  NODE_INNER_BIT = 0x80000000u };         // node link: inner -> NODE_INNER_BIT | first child; leaf -> primitive ref
+constexpr uint32_t kTopNodesMax = 0;                      // culling-tree nodes (whole levels) placed first and LDS-cached by large
+                                                          // scenes; 0 = off (measured slower on MI355X: a wave's step waits for its
+                                                          // deepest lane, so partial LDS hits do not shorten it; env TRT_TOP_NODES)
 
 struct Geometry {
     uint32_t kind;                           // 0 sphere, 1 quad
@@ -50,7 +54,8 @@ struct World {
 // touches per ray and are what small scenes copy into LDS; the reference tree follows.
 //   [culling nodes: 2m]  node i = elements 2i, 2i+1 (32 contiguous bytes = one sector per visit)
 //               2i:   (min.x, min.y, min.z, max.x)
-//               2i+1: (max.y, max.z, bits(skip), bits(prim))    prim: PRIM_NONE | kind bit | index
+//               2i+1: (max.y, max.z, bits(skip), bits(link))    link: NODE_INNER_BIT | first child, or kind bit | primitive index
+//               the first n_top_nodes are the tree's top levels, level by level; the rest follow in pre-order
 //   [sphere: ns] (center.xyz, radius)
 //   [quad plane 0: nq] (n.xyz, d)            Quad::hit stage 1   (quad.rs:34-37)
 //   [quad plane 1: nq] (corner.xyz, bits(material))
@@ -63,6 +68,7 @@ struct World {
 struct SceneLayout {
     uint32_t n_nodes;           // reference tree (2N-1)
     uint32_t n_cull_nodes;      // culling tree
+    uint32_t n_top_nodes;       // leading culling nodes that form its top levels (LDS-cached by large scenes)
     uint32_t n_spheres, n_quads, n_materials;
     uint32_t off_sphere, off_quad, off_material;                  // in 16-byte elements (culling nodes start at 0)
     uint32_t off_sphere_mat, off_material_kind;                   // in 4-byte elements from blob start

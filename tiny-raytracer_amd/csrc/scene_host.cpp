@@ -5,6 +5,7 @@
 #include "scene.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -258,20 +259,56 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     out.blob.assign(L.blob_bytes, 0);
     F4* f4 = reinterpret_cast<F4*>(out.blob.data());
     uint32_t* u32 = reinterpret_cast<uint32_t*>(out.blob.data());
-    auto pack_nodes = [&](F4* dst, const std::vector<Box>& boxes, const std::vector<int32_t>& prim_geo, const std::vector<int32_t>& skip) {
-        for (size_t i = 0; i < boxes.size(); i++) {
+    // Node links: a leaf carries its primitive reference, an inner node NODE_INNER_BIT | index of its first child;
+    // every node carries `skip`, the node to go to when its box is missed or its subtree is finished (END = count).
+    auto pack_nodes = [&](F4* dst, const std::vector<Box>& boxes, const std::vector<int32_t>& prim_geo, const std::vector<int32_t>& skip,
+                          const std::vector<uint32_t>& place) {
+        // place[i] = position of pre-order node i in the packed array (identity for the reference tree)
+        const size_t n = boxes.size();
+        auto at = [&](int32_t pre) -> uint32_t { return (size_t)pre >= n ? (uint32_t)n : place[(size_t)pre]; };
+        for (size_t i = 0; i < n; i++) {
             const Box& bx = boxes[i];
-            uint32_t prim = PRIM_NONE;
+            uint32_t link;
             if (prim_geo[i] >= 0) {
                 const Geometry& geo = w.geometries[(size_t)prim_geo[i]];
-                prim = local_index[(size_t)prim_geo[i]] | (geo.kind == 1 ? PRIM_QUAD_BIT : 0u);
+                link = local_index[(size_t)prim_geo[i]] | (geo.kind == 1 ? PRIM_QUAD_BIT : 0u);
+            } else {
+                link = NODE_INNER_BIT | at((int32_t)i + 1);          // first child follows in pre-order
             }
-            dst[2 * i] = F4{bx.lo.x, bx.lo.y, bx.lo.z, bx.hi.x};
-            dst[2 * i + 1] = F4{bx.hi.y, bx.hi.z, bitsf((uint32_t)skip[i]), bitsf(prim)};
+            const size_t o = place[i];
+            dst[2 * o] = F4{bx.lo.x, bx.lo.y, bx.lo.z, bx.hi.x};
+            dst[2 * o + 1] = F4{bx.hi.y, bx.hi.z, bitsf(at(skip[i])), bitsf(link)};
         }
     };
-    pack_nodes(f4, cb.node_box, cull_prim_geo, cb.node_skip);
-    pack_nodes(f4 + L.off_ref_nodes, b.node_box, b.node_prim, b.node_skip);
+    // Culling tree placement: the top levels first, level by level (they are what every ray touches, and what large
+    // scenes keep in LDS), then everything else in pre-order.
+    std::vector<uint32_t> cull_place(nc), ref_place(nn);
+    for (uint32_t i = 0; i < nn; i++) ref_place[i] = i;
+    uint32_t n_top = 0;
+    {
+        std::vector<uint32_t> depth(nc, 0);
+        std::vector<uint32_t> ends;                           // skip links of the open ancestors
+        uint32_t max_d = 0;
+        for (uint32_t i = 0; i < nc; i++) {
+            while (!ends.empty() && ends.back() <= i) ends.pop_back();
+            depth[i] = (uint32_t)ends.size();
+            if (depth[i] > max_d) max_d = depth[i];
+            if (cull_prim_geo[i] < 0) ends.push_back((uint32_t)cb.node_skip[i]);
+        }
+        std::vector<uint32_t> per_level(max_d + 1, 0);
+        for (uint32_t i = 0; i < nc; i++) per_level[depth[i]]++;
+        uint32_t top_levels = 0, total = 0, cap = kTopNodesMax;
+        if (const char* e = getenv("TRT_TOP_NODES")) cap = (uint32_t)atoi(e);        // tuning knob (placement only: results never change)
+        while (top_levels <= max_d && total + per_level[top_levels] <= cap) { total += per_level[top_levels]; top_levels++; }
+        n_top = total;
+        std::vector<uint32_t> next_in_level(top_levels, 0);
+        for (uint32_t d = 1; d < top_levels; d++) next_in_level[d] = next_in_level[d - 1] + per_level[d - 1];
+        uint32_t rest = n_top;
+        for (uint32_t i = 0; i < nc; i++) cull_place[i] = depth[i] < top_levels ? next_in_level[depth[i]]++ : rest++;
+    }
+    L.n_top_nodes = n_top;
+    pack_nodes(f4, cb.node_box, cull_prim_geo, cb.node_skip, cull_place);
+    pack_nodes(f4 + L.off_ref_nodes, b.node_box, b.node_prim, b.node_skip, ref_place);
     dump_tree(out.reference, b.node_box, b.node_prim, b.node_skip);
     dump_tree(out.culling, cb.node_box, cull_prim_geo, cb.node_skip);
     for (uint32_t i = 0; i < ns; i++) { f4[L.off_sphere + i] = spheres[i]; u32[L.off_sphere_mat + i] = sphere_mat[i]; }

@@ -24,6 +24,8 @@
 // One slot per pixel and samples walked in order keep the reference's accumulation order
 // (`pixels[idx] += color * (1/spp)`, imager.rs:50): the frame is bit-identical to the megakernel's
 // and to the CPU oracle's.
+#include <stdlib.h>
+
 #include "kernels.h"
 #include "rt_path.h"
 
@@ -80,20 +82,21 @@ TRT_DEV void store_path(const WfState& st, unsigned long long g, const Path& p, 
     st.rng[g] = make_uint2(p.rng.s0, p.rng.s1);
 }
 
-template <bool LDS, bool STATS>
-__global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, CameraDev cam, RenderArgs ra, WfState st,
+template <int MODE, bool STATS, int MINW = 1>
+__global__ __launch_bounds__(kWfThreads, MINW) void wavefront_kernel(SceneDev scd, CameraDev cam, RenderArgs ra, WfState st,
                                                                float* __restrict__ accum,
                                                                unsigned long long* __restrict__ counters, uint32_t tiles_x,
                                                                uint32_t serve_min) {
-    stage_scene_to_lds<LDS>(scd);
-    const SceneAcc<LDS> sc{scd.blob, scd.L};
-    WfLds& lds = *reinterpret_cast<WfLds*>(reinterpret_cast<char*>(g_lds) + (LDS ? scd.L.hot_bytes : 0u));
+    stage_scene_to_lds<MODE>(scd);
+    const SceneAcc<MODE> sc{scd.blob, scd.L};
+    WfLds& lds = *reinterpret_cast<WfLds*>(reinterpret_cast<char*>(g_lds) + sc.lds_bytes());
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     WfTile tile;
-    tile.x0 = (blockIdx.x % tiles_x) * kWfTileW;
-    tile.row0 = (blockIdx.x / tiles_x) * kWfTileH;
-    tile.slot0 = (unsigned long long)blockIdx.x * kWfSlots;
+    const uint32_t tile_id = xcd_tile(blockIdx.x, gridDim.x, ra.xcd_aware);
+    tile.x0 = (tile_id % tiles_x) * kWfTileW;
+    tile.row0 = (tile_id / tiles_x) * kWfTileH;
+    tile.slot0 = (unsigned long long)tile_id * kWfSlots;
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
@@ -163,12 +166,12 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
                     const uint32_t n_box = popc64(__builtin_amdgcn_ballot_w64(in_box));
                     const uint32_t n_wait = 64u - n_free - n_box;
                     if (n_box == 0u || n_wait >= serve_min) break;
-                    if (in_box) leaf = trav_box_step<LDS, STATS>(sc, ray, tr, ctr);
+                    if (in_box) leaf = trav_box_step<MODE, STATS>(sc, ray, tr, ctr);
                 }
                 // primitive tests for lanes standing on a leaf
                 if (slot != kNone && leaf != PRIM_NONE) {
                     if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-                    trav_leaf<LDS, STATS>(sc, ray, tr, leaf, ctr);
+                    trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr);
                     leaf = PRIM_NONE;
                 }
                 // retire finished walks: hit record to HBM, outcome bin to LDS
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(kWfThreads) void wavefront_kernel(SceneDev scd, Cam
                 p.rng = Rng{rs.x, rs.y};
                 uint32_t sample = __float_as_uint(co.w);
                 go_on = true;
-                if (shade_hit<LDS, STATS>(sc, p, __float_as_uint(d.w), a.w, background, ctr)) {
+                if (shade_hit<MODE, STATS>(sc, p, __float_as_uint(d.w), a.w, background, ctr)) {
                     uint32_t lx, ly;
                     slot_xy(slot, lx, ly);
                     const uint32_t x = tile.x0 + lx, row = tile.row0 + ly;
@@ -286,8 +289,7 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
     st.s2 = st.s1 + n_slots;
     st.s3 = st.s2 + n_slots;
     st.rng = reinterpret_cast<uint2*>(st.s3 + n_slots);
-    const bool lds = sc.L.hot_bytes <= kLdsSceneMaxBytes;
-    const size_t lds_bytes = (lds ? sc.L.hot_bytes : 0) + sizeof(WfLds);
+    const size_t lds_bytes = scene_lds_bytes(sc.L) + sizeof(WfLds);
     const dim3 grid(tiles_x * tiles_y), block(kWfThreads);
     if (serve_min == 0) serve_min = 24;
     auto go = [&](auto kernel) -> hipError_t {
@@ -298,8 +300,13 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
         hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, st, d_accum, d_counters, tiles_x, serve_min);
         return hipGetLastError();
     };
-    if (lds) return stats ? go(wavefront_kernel<true, true>) : go(wavefront_kernel<true, false>);
-    return stats ? go(wavefront_kernel<false, true>) : go(wavefront_kernel<false, false>);
+    switch (scene_mode(sc.L)) {
+        case MODE_LDS: return stats ? go(wavefront_kernel<MODE_LDS, true>) : go(wavefront_kernel<MODE_LDS, false>);
+        case MODE_HYBRID: return stats ? go(wavefront_kernel<MODE_HYBRID, true>) : go(wavefront_kernel<MODE_HYBRID, false>);
+        default:
+            if (getenv("TRT_MINW8")) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 8>) : go(wavefront_kernel<MODE_GLOBAL, false, 8>);
+            return stats ? go(wavefront_kernel<MODE_GLOBAL, true>) : go(wavefront_kernel<MODE_GLOBAL, false>);
+    }
 }
 
 }  // namespace trt

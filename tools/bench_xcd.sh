@@ -1,0 +1,20 @@
+#!/bin/bash
+out=gpurun_out/xcd.jsonl; : > $out
+run() { timeout -k 10 200 python bench.py --cpu-seconds 0 "$@" 2>/dev/null | tail -1 >> $out; }
+for x in "" 1; do
+  if [ -n "$x" ]; then export TRT_NO_XCD_REMAP=1; fi
+  echo "{\"top\": \"no_xcd_remap=$x\"}" >> $out
+  run --scene sphere_grid --width 3840 --height 2160 --spp-per-step 4 --steps 2 --warmup 1 --backend megakernel
+  TRT_WF_SERVE_MIN=8 run --scene sphere_grid --width 3840 --height 2160 --spp-per-step 8 --steps 1 --warmup 1 --backend wavefront
+  run --scene cornell --spp-per-step 64 --steps 2 --warmup 1 --backend megakernel
+done
+run --scene cornell --spp-per-step 256 --steps 1 --warmup 1 --backend megakernel
+run --scene random_spheres --width 1920 --height 1080 --spp-per-step 256 --steps 1 --warmup 1 --backend megakernel
+python - <<'PY'
+import json
+for ln in open("gpurun_out/xcd.jsonl"):
+    try: d=json.loads(ln)
+    except Exception: print("bad line", ln[:80]); continue
+    if "top" in d: print(d["top"]); continue
+    r=d["roofline"]; print(d["config"]["workload"][:70].ljust(72), "%9.1f Mray/s  %7.2f ms/step  frac %.3f" % (d["value"], d["ms_per_step"], r["frac"]))
+PY

@@ -9,15 +9,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 trt = importlib.import_module("tiny-raytracer_amd")
 
-CASES = [("cornell", lambda: trt.scenes.cornell(1024, 1024), 8), ("random_spheres", lambda: trt.scenes.random_spheres(960, 540), 8),
-         ("sphere_grid100k", lambda: trt.scenes.sphere_grid(100000, 960, 540), 2)]
+CASES = [("cornell", lambda: trt.scenes.cornell(1024, 1024), 64), ("random_spheres", lambda: trt.scenes.random_spheres(960, 540), 64),
+         ("sphere_grid100k", lambda: trt.scenes.sphere_grid(100000, 960, 540), 8)]
+BACKEND = int(os.environ.get("DIAG_BACKEND", "0"))
 if len(sys.argv) > 1:
     CASES = [c for c in CASES if c[0] in sys.argv[1:]]
 for name, mk, spp in CASES:
     desc = mk()
     w, cam = trt.world_from_description(desc)
-    r = trt.Renderer(spp, 1, 50, False, desc["background"])
-    r.render(cam, w, collect_stats=True)
+    r = trt.Renderer(spp, 1, 50, False, desc["background"], backend=BACKEND)
+    r.render(cam, w, collect_stats=2)               # counting kernel on the culling tree: the tests actually performed
     s = r.last_stats
     rounds, steps, leafs, gens = s["wave_trips"]
     prim = s["sphere_tests"] + s["quad_plane_tests"]
