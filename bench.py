@@ -62,7 +62,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=256)
-    ap.add_argument("--backend", default="megakernel", choices=["megakernel", "wavefront"])
+    ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront"],
+                    help="auto = megakernel when the scene fits LDS (Cornell, random-spheres), wavefront otherwise")
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--depth", type=int, default=50)
@@ -99,6 +100,8 @@ def main():
     world, cam = trt.world_from_description(desc)
     scene = world.get_bvh()
     total_spp = 4096
+    if args.backend == "auto":
+        args.backend = "megakernel" if scene.info()["lds_bytes"] > 0 else "wavefront"
     backend = trt.BACKEND_WAVEFRONT if args.backend == "wavefront" else trt.BACKEND_MEGAKERNEL
     renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1, backend=backend)
     kernel_name = "trt::wavefront_kernel" if args.backend == "wavefront" else "trt::megakernel"

@@ -112,7 +112,9 @@ int trt_camera_init(trt_camera *out, float focus_distance, float defocus_angle_d
 /* ---- Renderer (renderer/renderer.rs:12-35) ---- */
 enum trt_backend {
     TRT_BACKEND_MEGAKERNEL = 0,   /* one persistent lane per pixel, whole bounce loop in one kernel */
-    TRT_BACKEND_WAVEFRONT = 1     /* ray queues in HBM: generate / extend / shade-by-material / compact */
+    TRT_BACKEND_WAVEFRONT = 1,    /* workgroup-resident wavefront: path state SoA in HBM, ray queues in LDS,
+                                     generate / extend / sort-by-material / shade as phases of one persistent kernel */
+    TRT_BACKEND_AUTO = 2          /* megakernel when the scene fits LDS, wavefront otherwise (measured crossover) */
 };
 typedef struct {
     uint32_t samples_per_pixel;   /* Renderer::samples_per_pixel: fixes the 1/spp scale (imager.rs:35) */

@@ -8,13 +8,13 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtinyrt.so")
+LIB_PATH = os.environ.get("TRT_LIB_PATH") or os.path.join(_HERE, "libtinyrt.so")     # override: A/B of two builds
 CSRC = os.path.join(_HERE, "csrc")
 
 TRT_OK = 0
 ERR_INVALID_ARG, ERR_DUPLICATE, ERR_NOT_FOUND, ERR_HIP, ERR_NO_DEVICE, ERR_OOM = -1, -2, -3, -4, -5, -6
 LAMBERTIAN, METAL, DIELECTRIC, LIGHT = 0, 1, 2, 3
-BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT = 0, 1
+BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, BACKEND_AUTO = 0, 1, 2
 
 
 class Vec3(C.Structure):

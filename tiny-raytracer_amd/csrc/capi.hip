@@ -92,7 +92,7 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     if (p->samples_per_pixel == 0) return fail(TRT_ERR_INVALID_ARG, "samples_per_pixel must be positive");
     uint32_t s1 = p->sample_end == 0 ? p->samples_per_pixel : p->sample_end;
     if (p->sample_begin > s1 || s1 > p->samples_per_pixel) return fail(TRT_ERR_INVALID_ARG, "sample range must satisfy begin <= end <= samples_per_pixel");
-    if (p->backend != TRT_BACKEND_MEGAKERNEL && p->backend != TRT_BACKEND_WAVEFRONT) return fail(TRT_ERR_INVALID_ARG, "unknown backend");
+    if (p->backend > TRT_BACKEND_AUTO) return fail(TRT_ERR_INVALID_ARG, "unknown backend");
     ra.background[0] = p->background.x; ra.background[1] = p->background.y; ra.background[2] = p->background.z;
     ra.inv_spp = 1.0f / (float)p->samples_per_pixel;
     ra.max_bounces = p->max_bounces;
@@ -137,7 +137,8 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
         if (!ra.accumulate && bytes) TRT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
         return TRT_OK;
     }
-    if (p->backend == TRT_BACKEND_WAVEFRONT) {
+    const bool wavefront = p->backend == TRT_BACKEND_WAVEFRONT || (p->backend == TRT_BACKEND_AUTO && scene_mode(sc.L) != 1);
+    if (wavefront) {
         // path-state workspace: 72 B per pixel slot, cached on the scene handle per device.  One wavefront render at a
         // time per scene handle and device (the workspace is shared); the megakernel has no such restriction.
         int dev = 0;

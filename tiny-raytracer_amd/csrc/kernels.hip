@@ -49,15 +49,35 @@ __global__ __launch_bounds__(256, MINW) void megakernel(SceneDev scd, CameraDev 
     bool fresh = true;                       // lane needs a new primary ray
     Path p;
     p.remain = 0u;
+    // One primary ray kept ahead per lane.  A path ends every ~7 bounces, so in any one trip only a few lanes need a
+    // new primary ray and generating it on demand runs that code at ~10 % lane occupancy.  Instead, whenever some lane
+    // needs a ray and has none in stock, EVERY lane without stock generates the ray of the next sample it will need
+    // (its stream depends on (seed, pixel, sample) only), so the generator runs less often and fuller.
+    Ray next_ray;
+    Rng next_rng;
+    bool stocked = false;
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
 
     while (__builtin_amdgcn_ballot_w64(alive) != 0ull) {
+        if (__builtin_amdgcn_ballot_w64(alive && fresh && !stocked) != 0ull) {
+            const uint32_t s_next = fresh ? s : s + 1u;                             // the sample this lane starts next
+            if (alive && !stocked && s_next < ra.sample_end) {
+                if constexpr (STATS) { if (first_active_lane()) ctr.w_gen++; }
+                next_rng = rng_seed(ra.seed_key, y * cam.width + x, s_next);
+                next_ray = primary_ray(cam, x, y, next_rng);
+                stocked = true;
+            }
+        }
         if (alive) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
-            if (fresh) {
-                if constexpr (STATS) { if (first_active_lane()) ctr.w_gen++; }
-                path_begin(p, cam, ra, x, y, s);
+            if (fresh) {                                                            // cpu.rs:42-45
+                p.ray = next_ray;
+                p.rng = next_rng;
+                p.color = v3(0.0f, 0.0f, 0.0f);
+                p.atten = v3(1.0f, 1.0f, 1.0f);
+                p.remain = ra.max_bounces;
+                stocked = false;
                 fresh = false;
                 n_samples++;
             }
@@ -138,7 +158,18 @@ hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const Ren
     const size_t lds_bytes = scene_lds_bytes(sc.L);
     auto go = [&](auto kernel) { return launch(kernel, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x); };
     switch (scene_mode(sc.L)) {
-        case MODE_LDS: return stats ? go(megakernel<MODE_LDS, true>) : go(megakernel<MODE_LDS, false>);
+        case MODE_LDS: {
+            // Register budget by launch bound.  The kernel wants 98 VGPRs (4 waves/SIMD); capping it buys occupancy at the
+            // price of a few spilled dwords.  Measured on Cornell 2048^2 (Mray/s): 4 waves 20.7 k, 5: 22.5 k, 6: 23.3 k,
+            // 7: 23.9 k, 8: 23.5 k.  Seven workgroups per CU need the LDS scene copy to stay under 160 KiB / 7; larger
+            // copies are LDS-limited anyway and take the 5-wave variant (random-spheres: 5 waves 7.8 k vs 6 waves 7.5 k).
+            int w = sc.L.hot_bytes <= 20u * 1024u ? 7 : 5;
+            if (const char* e = getenv("TRT_MINW")) w = atoi(e);
+            if (w >= 8) return stats ? go(megakernel<MODE_LDS, true, 8>) : go(megakernel<MODE_LDS, false, 8>);
+            if (w == 7) return stats ? go(megakernel<MODE_LDS, true, 7>) : go(megakernel<MODE_LDS, false, 7>);
+            if (w == 6) return stats ? go(megakernel<MODE_LDS, true, 6>) : go(megakernel<MODE_LDS, false, 6>);
+            return stats ? go(megakernel<MODE_LDS, true, 5>) : go(megakernel<MODE_LDS, false, 5>);
+        }
         case MODE_HYBRID: return stats ? go(megakernel<MODE_HYBRID, true>) : go(megakernel<MODE_HYBRID, false>);
         default:
             if (getenv("TRT_MINW8")) return stats ? go(megakernel<MODE_GLOBAL, true, 8>) : go(megakernel<MODE_GLOBAL, false, 8>);
