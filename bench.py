@@ -62,7 +62,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=256)
-    ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront"],
+    ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront", "pooled"],
                     help="auto = megakernel when the scene fits LDS (Cornell, random-spheres), wavefront otherwise")
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
@@ -102,9 +102,9 @@ def main():
     total_spp = 4096
     if args.backend == "auto":
         args.backend = "megakernel" if scene.info()["lds_bytes"] > 0 else "wavefront"
-    backend = trt.BACKEND_WAVEFRONT if args.backend == "wavefront" else trt.BACKEND_MEGAKERNEL
+    backend = {"wavefront": trt.BACKEND_WAVEFRONT, "pooled": trt.BACKEND_POOLED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
     renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1, backend=backend)
-    kernel_name = "trt::wavefront_kernel" if args.backend == "wavefront" else "trt::megakernel"
+    kernel_name = {"wavefront": "trt::wavefront_kernel", "pooled": "trt::pooled_kernel"}.get(args.backend, "trt::megakernel")
 
     lay = tiles.band_layout(H, world_size, rank)
     band = dict(band_rows=lay["band_rows"], band_stride=lay["band_stride"], band_offset=lay["band_offset"],

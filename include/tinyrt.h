@@ -114,7 +114,8 @@ enum trt_backend {
     TRT_BACKEND_MEGAKERNEL = 0,   /* one persistent lane per pixel, whole bounce loop in one kernel */
     TRT_BACKEND_WAVEFRONT = 1,    /* workgroup-resident wavefront: path state SoA in HBM, ray queues in LDS,
                                      generate / extend / sort-by-material / shade as phases of one persistent kernel */
-    TRT_BACKEND_AUTO = 2          /* megakernel when the scene fits LDS, wavefront otherwise (measured crossover) */
+    TRT_BACKEND_AUTO = 2,         /* best measured backend for the scene: fits LDS -> a megakernel, else wavefront */
+    TRT_BACKEND_POOLED = 3        /* megakernel with two pixels per lane whose rays are traced from a per-wave pool in LDS */
 };
 typedef struct {
     uint32_t samples_per_pixel;   /* Renderer::samples_per_pixel: fixes the 1/spp scale (imager.rs:35) */

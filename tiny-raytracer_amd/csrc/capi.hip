@@ -92,7 +92,7 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     if (p->samples_per_pixel == 0) return fail(TRT_ERR_INVALID_ARG, "samples_per_pixel must be positive");
     uint32_t s1 = p->sample_end == 0 ? p->samples_per_pixel : p->sample_end;
     if (p->sample_begin > s1 || s1 > p->samples_per_pixel) return fail(TRT_ERR_INVALID_ARG, "sample range must satisfy begin <= end <= samples_per_pixel");
-    if (p->backend > TRT_BACKEND_AUTO) return fail(TRT_ERR_INVALID_ARG, "unknown backend");
+    if (p->backend > TRT_BACKEND_POOLED) return fail(TRT_ERR_INVALID_ARG, "unknown backend");
     ra.background[0] = p->background.x; ra.background[1] = p->background.y; ra.background[2] = p->background.z;
     ra.inv_spp = 1.0f / (float)p->samples_per_pixel;
     ra.max_bounces = p->max_bounces;
@@ -159,6 +159,12 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
         if (const char* e = getenv("TRT_WF_SERVE_MIN")) serve_min = (uint32_t)atoi(e);
         TRT_HIP(launch_wavefront(sc, cd, ra, ws, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0,
                                  serve_min, stream));
+        return TRT_OK;
+    }
+    if (p->backend == TRT_BACKEND_POOLED) {
+        uint32_t serve_min = 0;
+        if (const char* e = getenv("TRT_POOL_SERVE_MIN")) serve_min = (uint32_t)atoi(e);
+        TRT_HIP(launch_pooled(sc, cd, ra, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, serve_min, stream));
         return TRT_OK;
     }
     TRT_HIP(launch_megakernel(sc, cd, ra, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));

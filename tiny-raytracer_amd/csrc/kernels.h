@@ -65,6 +65,10 @@ size_t wavefront_workspace_bytes(uint32_t width, uint32_t rows);
 hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
                             unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream);
 
+// Pooled megakernel (pooled.hip): two pixels per lane, rays traced from a per-wave pool in LDS.
+hipError_t launch_pooled(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
+                         unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream);
+
 // Sampler plug-in form: n caller-supplied rays.
 hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out,
                                const RenderArgs& ra, unsigned long long* d_counters, bool stats, hipStream_t stream);
