@@ -19,14 +19,14 @@
 namespace trt {
 
 // ------------------------------------------------------------------------------------------------
-// Megakernel.  Workgroup = 256 lanes = a 16x16 pixel tile; each wave owns an 8x8 sub-tile so the
+// Megakernel.  Workgroup = THREADS lanes = a 16 x (THREADS/16) pixel tile; each wave owns an 8x8 sub-tile so the
 // 64 paths of a wave see similar geometry.  A lane is done when its pixel has had samples
 // [sample_begin, sample_end); the wave leaves the loop when every lane is done.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kTile = 16;
+constexpr uint32_t kTileW = 16;          // tile height = THREADS / 16: 16 rows for 256 lanes, 32 for 512
 
-template <int MODE, bool STATS, int MINW = 1>
-__global__ __launch_bounds__(256, MINW) void megakernel(SceneDev scd, CameraDev cam, RenderArgs ra, float* __restrict__ accum,
+template <int MODE, bool STATS, int MINW = 1, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, MINW) void megakernel(SceneDev scd, CameraDev cam, RenderArgs ra, float* __restrict__ accum,
                                                   unsigned long long* __restrict__ counters, uint32_t tiles_x) {
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(256, MINW) void megakernel(SceneDev scd, CameraDev 
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x, ra.xcd_aware);
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
-    const uint32_t x = tile_x * kTile + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t row = tile_y * kTile + (wave >> 1) * 8u + (lane >> 3);          // local row
+    const uint32_t x = tile_x * kTileW + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t row = tile_y * (uint32_t)(THREADS / 16) + (wave >> 1) * 8u + (lane >> 3);    // local row
     const bool in_image = x < cam.width && row < ra.rows_local;
     const uint32_t y = image_row(ra, row);                                          // image row: keys the RNG
     float* out = accum + 3ull * ((unsigned long long)row * cam.width + x);
@@ -152,24 +152,31 @@ static hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
 
 hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
                              unsigned long long* d_counters, bool stats, hipStream_t stream) {
-    const uint32_t tiles_x = (cam.width + kTile - 1) / kTile, tiles_y = (ra.rows_local + kTile - 1) / kTile;
-    if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
-    const dim3 grid(tiles_x * tiles_y), block(256);
+    // Workgroup size and register budget.  The kernel wants 98 VGPRs (4 waves/SIMD); capping it by launch bound buys
+    // occupancy for a few spilled dwords.  Measured on Cornell 2048^2 (Gray/s): 4 waves 20.7, 5: 22.5, 6: 23.3, 7: 23.9,
+    // 8: 23.5.  A workgroup's LDS scene copy is shared by its waves, so scenes with a big copy (random-spheres: 50 KB,
+    // three copies per CU) use 512-lane workgroups: 3 x 8 waves per CU instead of 3 x 4.
     const size_t lds_bytes = scene_lds_bytes(sc.L);
+    const int mode = scene_mode(sc.L);
+    int threads = (mode == MODE_LDS && sc.L.hot_bytes > 20u * 1024u) ? 512 : 256;
+    int w = mode != MODE_LDS ? 1 : (threads == 512 ? 6 : 7);
+    if (const char* e = getenv("TRT_MEGA_THREADS")) threads = atoi(e) == 512 ? 512 : 256;
+    if (const char* e = getenv("TRT_MINW")) w = atoi(e);
+    const uint32_t tile_h = (uint32_t)threads / 16u;
+    const uint32_t tiles_x = (cam.width + kTileW - 1) / kTileW, tiles_y = (ra.rows_local + tile_h - 1) / tile_h;
+    if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
+    const dim3 grid(tiles_x * tiles_y), block((uint32_t)threads);
     auto go = [&](auto kernel) { return launch(kernel, grid, block, lds_bytes, stream, sc, cam, ra, d_accum, d_counters, tiles_x); };
-    switch (scene_mode(sc.L)) {
-        case MODE_LDS: {
-            // Register budget by launch bound.  The kernel wants 98 VGPRs (4 waves/SIMD); capping it buys occupancy at the
-            // price of a few spilled dwords.  Measured on Cornell 2048^2 (Mray/s): 4 waves 20.7 k, 5: 22.5 k, 6: 23.3 k,
-            // 7: 23.9 k, 8: 23.5 k.  Seven workgroups per CU need the LDS scene copy to stay under 160 KiB / 7; larger
-            // copies are LDS-limited anyway and take the 5-wave variant (random-spheres: 5 waves 7.8 k vs 6 waves 7.5 k).
-            int w = sc.L.hot_bytes <= 20u * 1024u ? 7 : 5;
-            if (const char* e = getenv("TRT_MINW")) w = atoi(e);
+    switch (mode) {
+        case MODE_LDS:
+            if (threads == 512) {
+                if (w >= 6) return stats ? go(megakernel<MODE_LDS, true, 6, 512>) : go(megakernel<MODE_LDS, false, 6, 512>);
+                return stats ? go(megakernel<MODE_LDS, true, 5, 512>) : go(megakernel<MODE_LDS, false, 5, 512>);
+            }
             if (w >= 8) return stats ? go(megakernel<MODE_LDS, true, 8>) : go(megakernel<MODE_LDS, false, 8>);
             if (w == 7) return stats ? go(megakernel<MODE_LDS, true, 7>) : go(megakernel<MODE_LDS, false, 7>);
             if (w == 6) return stats ? go(megakernel<MODE_LDS, true, 6>) : go(megakernel<MODE_LDS, false, 6>);
             return stats ? go(megakernel<MODE_LDS, true, 5>) : go(megakernel<MODE_LDS, false, 5>);
-        }
         case MODE_HYBRID: return stats ? go(megakernel<MODE_HYBRID, true>) : go(megakernel<MODE_HYBRID, false>);
         default:
             if (getenv("TRT_MINW8")) return stats ? go(megakernel<MODE_GLOBAL, true, 8>) : go(megakernel<MODE_GLOBAL, false, 8>);

@@ -2,10 +2,10 @@
 out=gpurun_out/ab.jsonl; : > $out
 run() { timeout -k 10 300 python bench.py --cpu-seconds 0 --no-roofline-pass "$@" 2>/dev/null | tail -1 >> $out; }
 for rep in 1 2; do
-for v in 5 6 7 8; do
-  export TRT_MINW=$v
-  echo "{\"top\": \"minw $v\"}" >> $out
-  run --scene cornell --spp-per-step 128 --steps 2 --warmup 1
+for v in "256 5" "512 5" "512 6"; do
+  set -- $v; export TRT_MEGA_THREADS=$1 TRT_MINW=$2
+  echo "{\"top\": \"threads $1 minw $2\"}" >> $out
+  run --scene random_spheres --width 1920 --height 1080 --spp-per-step 128 --steps 2 --warmup 1
 done; done
 python - <<'PY'
 import json
