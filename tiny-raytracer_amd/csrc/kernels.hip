@@ -160,7 +160,7 @@ hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const Ren
     const int mode = scene_mode(sc.L);
     int threads = (mode == MODE_LDS && sc.L.hot_bytes > 20u * 1024u) ? 512 : 256;
     int w = mode != MODE_LDS ? 1 : (threads == 512 ? 6 : 7);
-    if (const char* e = getenv("TRT_MEGA_THREADS")) threads = atoi(e) == 512 ? 512 : 256;
+    if (const char* e = getenv("TRT_MEGA_THREADS")) threads = (mode == MODE_LDS && atoi(e) == 512) ? 512 : 256;   // only MODE_LDS has 512-lane instances
     if (const char* e = getenv("TRT_MINW")) w = atoi(e);
     const uint32_t tile_h = (uint32_t)threads / 16u;
     const uint32_t tiles_x = (cam.width + kTileW - 1) / kTileW, tiles_y = (ra.rows_local + tile_h - 1) / tile_h;
