@@ -32,12 +32,34 @@ def algorithmic_bytes(c, pixels):
             + 20 * c["shades"] + 12 * pixels)
 
 
+def usable_cores():
+    """Host cores this process may really use: the affinity mask, capped by the cgroup CPU quota (a GPU box shows all
+    of the host's CPUs in the mask but grants one GPU slot a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                parts = f.read().split()
+            if path.endswith("cpu.max"):
+                if parts[0] != "max":
+                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+            else:
+                quota = int(parts[0])
+                if quota > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                        n = min(n, max(1, quota // int(f.read())))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_baseline(trt, desc, depth, budget_s):
     """The CPU oracle (a port of the reference's CPU path) on a bounded sample of the same workload: whole-image
     passes of 1 spp, all host cores, until `budget_s` seconds have been spent."""
     from oracle import orc
     import numpy as np
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     world, cam = orc.world_from_description(desc)
     orc.lib.orc_world_build(world._h)
     acc = np.zeros((cam.height, cam.width, 3), np.float32)
