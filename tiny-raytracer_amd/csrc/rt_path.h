@@ -113,12 +113,16 @@ TRT_DEV Trav trav_begin(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree)
 template <int MODE, bool STATS>
 TRT_DEV uint32_t trav_box_step(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
     float4 na, nb;
-    if (__builtin_expect(tr.ref, 0)) sc.ref_node(tr.i, na, nb);
-    else sc.node(tr.i, na, nb);
-    if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
     bool pass;
-    if (__builtin_expect(tr.fast, 1)) pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
-    else pass = slab_exact(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
+    if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+    if (__builtin_expect(!tr.ref, 1)) {                       // common case: culling tree, finite ray (ref == false implies fast)
+        sc.node(tr.i, na, nb);
+        pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
+    } else {
+        sc.ref_node(tr.i, na, nb);
+        if (tr.fast) pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
+        else pass = slab_exact(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
+    }
     const uint32_t link = __float_as_uint(nb.w);
     const bool inner = (link & NODE_INNER_BIT) != 0u;
     tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);     // descend, or skip (a leaf's skip is its successor)

@@ -291,7 +291,7 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
     st.rng = reinterpret_cast<uint2*>(st.s3 + n_slots);
     const size_t lds_bytes = scene_lds_bytes(sc.L) + sizeof(WfLds);
     const dim3 grid(tiles_x * tiles_y), block(kWfThreads);
-    if (serve_min == 0) serve_min = 24;
+    if (serve_min == 0) serve_min = 12;        // flat optimum 8..24 on the 100 k-sphere scene
     auto go = [&](auto kernel) -> hipError_t {
         if (lds_bytes > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -303,9 +303,14 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
     switch (scene_mode(sc.L)) {
         case MODE_LDS: return stats ? go(wavefront_kernel<MODE_LDS, true>) : go(wavefront_kernel<MODE_LDS, false>);
         case MODE_HYBRID: return stats ? go(wavefront_kernel<MODE_HYBRID, true>) : go(wavefront_kernel<MODE_HYBRID, false>);
-        default:
-            if (getenv("TRT_MINW8")) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 8>) : go(wavefront_kernel<MODE_GLOBAL, false, 8>);
+        default: {
+            int w = 6;                              // 80 VGPRs, 12 B of scratch: +2 % over the 87-VGPR / 5-wave allocation; 7, 8: slower
+            if (const char* e = getenv("TRT_WF_MINW")) w = atoi(e);
+            if (w >= 8) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 8>) : go(wavefront_kernel<MODE_GLOBAL, false, 8>);
+            if (w == 7) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 7>) : go(wavefront_kernel<MODE_GLOBAL, false, 7>);
+            if (w == 6) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 6>) : go(wavefront_kernel<MODE_GLOBAL, false, 6>);
             return stats ? go(wavefront_kernel<MODE_GLOBAL, true>) : go(wavefront_kernel<MODE_GLOBAL, false>);
+        }
     }
 }
 
