@@ -84,8 +84,8 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=256)
-    ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront", "pooled"],
-                    help="auto = megakernel when the scene fits LDS (Cornell, random-spheres), wavefront otherwise")
+    ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront", "pooled", "streamed"],
+                    help="auto = the library's default (streamed)")
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--depth", type=int, default=50)
@@ -123,10 +123,10 @@ def main():
     scene = world.get_bvh()
     total_spp = 4096
     if args.backend == "auto":
-        args.backend = "megakernel" if scene.info()["lds_bytes"] > 0 else "wavefront"
-    backend = {"wavefront": trt.BACKEND_WAVEFRONT, "pooled": trt.BACKEND_POOLED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
+        args.backend = "streamed"
+    backend = {"wavefront": trt.BACKEND_WAVEFRONT, "pooled": trt.BACKEND_POOLED, "streamed": trt.BACKEND_STREAMED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
     renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1, backend=backend)
-    kernel_name = {"wavefront": "trt::wavefront_kernel", "pooled": "trt::pooled_kernel"}.get(args.backend, "trt::megakernel")
+    kernel_name = {"wavefront": "trt::wavefront_kernel", "pooled": "trt::pooled_kernel", "streamed": "trt::stream_sample_kernel"}.get(args.backend, "trt::megakernel")
 
     lay = tiles.band_layout(H, world_size, rank)
     band = dict(band_rows=lay["band_rows"], band_stride=lay["band_stride"], band_offset=lay["band_offset"],
@@ -184,8 +184,13 @@ def main():
         c = dict(zip(("samples", "rays", "node_tests", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"),
                      [int(v) for v in sctr[:7].tolist()]))
         assert c["rays"] == int(ctr[1].item()), "counting variant traced a different number of rays"
-        bytes_per_launch = algorithmic_bytes(c, 0) / args.steps + 12 * rows_local * W
-        avg_ms = sum(launch_ms) / len(launch_ms)
+        # the streamed backend splits a step into chunks: one dominant-kernel launch (+ one small fold launch) per chunk
+        launches_per_step = 1
+        if args.backend == "streamed":
+            chunk = trt.lib.trt_streamed_chunk_spp(W, rows_local)
+            launches_per_step = (S + chunk - 1) // chunk
+        bytes_per_launch = (algorithmic_bytes(c, 0) / args.steps + 12 * rows_local * W) / launches_per_step
+        avg_ms = sum(launch_ms) / len(launch_ms) / launches_per_step
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -197,6 +202,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4),
+                    "launches_per_step": launches_per_step,
                     "bytes_per_ray": round(algorithmic_bytes(c, 0) / max(c["rays"], 1), 2),
                     "rays_per_sample": round(c["rays"] / max(c["samples"], 1), 3)}
 

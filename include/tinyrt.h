@@ -114,8 +114,9 @@ enum trt_backend {
     TRT_BACKEND_MEGAKERNEL = 0,   /* one persistent lane per pixel, whole bounce loop in one kernel */
     TRT_BACKEND_WAVEFRONT = 1,    /* workgroup-resident wavefront: path state SoA in HBM, ray queues in LDS,
                                      generate / extend / sort-by-material / shade as phases of one persistent kernel */
-    TRT_BACKEND_AUTO = 2,         /* best measured backend for the scene: fits LDS -> a megakernel, else wavefront */
-    TRT_BACKEND_POOLED = 3        /* megakernel with two pixels per lane whose rays are traced from a per-wave pool in LDS */
+    TRT_BACKEND_AUTO = 2,         /* the fastest measured backend (currently TRT_BACKEND_STREAMED for every scene) */
+    TRT_BACKEND_POOLED = 3,       /* megakernel with two pixels per lane whose rays are traced from a per-wave pool in LDS */
+    TRT_BACKEND_STREAMED = 4      /* samples as work items pulled by persistent waves; radiances folded per pixel in sample order */
 };
 typedef struct {
     uint32_t samples_per_pixel;   /* Renderer::samples_per_pixel: fixes the 1/spp scale (imager.rs:35) */
@@ -168,6 +169,10 @@ int trt_sample_batch(trt_scene *s, const trt_sample_point *in, uint32_t n, trt_s
 /* Imager finalisation + Image -> RgbImage (imager.rs:52-53; utils/image.rs:92-111): c^(1/gamma),
  * clamp to [0, 0.999], *255, truncate; NaN -> 0.  HOST buffers, npixels*3 each. */
 int trt_tonemap_u8(const float *accum, uint32_t npixels, float gamma, uint8_t *rgb);
+
+/* Samples per pixel the streamed backend traces per kernel launch for an image of this size (it splits longer sample
+ * ranges into such chunks; one chunk = one `trt::stream_sample_kernel` launch + one fold launch). */
+uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows);
 
 /* ---- library ---- */
 const char *trt_last_error(void);

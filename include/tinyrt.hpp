@@ -142,7 +142,7 @@ private:
 class Renderer {
 public:
     Renderer(uint32_t samples_per_pixel, uint32_t num_sampler_threads, uint32_t max_bounces, bool progressbar,
-             std::optional<Vec3> background_color, uint32_t seed = 1, uint32_t backend = TRT_BACKEND_MEGAKERNEL) {
+             std::optional<Vec3> background_color, uint32_t seed = 1, uint32_t backend = TRT_BACKEND_AUTO) {
         (void)num_sampler_threads;     // the GPU needs no sampler-task count; kept for signature parity
         (void)progressbar;
         params_ = trt_render_params{};

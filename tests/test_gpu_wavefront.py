@@ -93,7 +93,7 @@ def test_bounce_budgets_and_progressive(trt, orc):
     a = r.render(pcam, pw, sample_begin=0, sample_end=3).data
     b = r.render(pcam, pw, accum=a.copy(), sample_begin=3, sample_end=8, accumulate=1).data
     assert_bit_equal(b, one, "wavefront progressive")
-    mega = trt.Renderer(8, 1, 10, False, desc["background"]).render(pcam, pw).data
+    mega = trt.Renderer(8, 1, 10, False, desc["background"], backend=0).render(pcam, pw).data
     assert_bit_equal(one, mega, "wavefront vs megakernel")
 
 
@@ -122,5 +122,5 @@ def test_full_size_random_spheres_1080p_properties(trt):
     assert st["samples"] == 1920 * 1080 * 4 and st["samples"] <= st["rays"] <= 50 * st["samples"]
     again = r.render(pcam, pw).data
     assert_bit_equal(again, full, "wavefront determinism")
-    mega = trt.Renderer(4, 1, 50, False, desc["background"]).render(pcam, pw).data
+    mega = trt.Renderer(4, 1, 50, False, desc["background"], backend=0).render(pcam, pw).data
     assert_bit_equal(full, mega, "wavefront vs megakernel 1080p")

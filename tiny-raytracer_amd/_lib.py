@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 TRT_OK = 0
 ERR_INVALID_ARG, ERR_DUPLICATE, ERR_NOT_FOUND, ERR_HIP, ERR_NO_DEVICE, ERR_OOM = -1, -2, -3, -4, -5, -6
 LAMBERTIAN, METAL, DIELECTRIC, LIGHT = 0, 1, 2, 3
-BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, BACKEND_AUTO, BACKEND_POOLED = 0, 1, 2, 3
+BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, BACKEND_AUTO, BACKEND_POOLED, BACKEND_STREAMED = 0, 1, 2, 3, 4
 
 
 class Vec3(C.Structure):
@@ -96,6 +96,7 @@ SIGNATURES = {
                                     C.c_void_p]),
     "trt_sample_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, Vec3, C.c_uint32,
                                    C.POINTER(Stats)]),
+    "trt_streamed_chunk_spp": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "trt_tonemap_u8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]),
     "trt_last_error": (C.c_char_p, []),
     "trt_device_count": (C.c_int, []),

@@ -169,7 +169,7 @@ class Image:
 
 class Renderer:
     def __init__(self, samples_per_pixel, num_sampler_threads=1, max_bounces=50, progressbar=False,
-                 background_color=None, seed=1, backend=BACKEND_MEGAKERNEL):
+                 background_color=None, seed=1, backend=_lib.BACKEND_AUTO):
         self.samples_per_pixel = int(samples_per_pixel)
         self.num_sampler_threads = int(num_sampler_threads)      # kept for signature parity; the GPU ignores it
         self.max_bounces = int(max_bounces)

@@ -92,7 +92,7 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     if (p->samples_per_pixel == 0) return fail(TRT_ERR_INVALID_ARG, "samples_per_pixel must be positive");
     uint32_t s1 = p->sample_end == 0 ? p->samples_per_pixel : p->sample_end;
     if (p->sample_begin > s1 || s1 > p->samples_per_pixel) return fail(TRT_ERR_INVALID_ARG, "sample range must satisfy begin <= end <= samples_per_pixel");
-    if (p->backend > TRT_BACKEND_POOLED) return fail(TRT_ERR_INVALID_ARG, "unknown backend");
+    if (p->backend > TRT_BACKEND_STREAMED) return fail(TRT_ERR_INVALID_ARG, "unknown backend");
     ra.background[0] = p->background.x; ra.background[1] = p->background.y; ra.background[2] = p->background.z;
     ra.inv_spp = 1.0f / (float)p->samples_per_pixel;
     ra.max_bounces = p->max_bounces;
@@ -137,13 +137,15 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
         if (!ra.accumulate && bytes) TRT_HIP(hipMemsetAsync(d_accum, 0, bytes, stream));
         return TRT_OK;
     }
-    const bool wavefront = p->backend == TRT_BACKEND_WAVEFRONT || (p->backend == TRT_BACKEND_AUTO && scene_mode(sc.L) != 1);
-    if (wavefront) {
-        // path-state workspace: 72 B per pixel slot, cached on the scene handle per device.  One wavefront render at a
-        // time per scene handle and device (the workspace is shared); the megakernel has no such restriction.
+    const bool wavefront = p->backend == TRT_BACKEND_WAVEFRONT;
+    const bool streamed = p->backend == TRT_BACKEND_STREAMED || p->backend == TRT_BACKEND_AUTO;     // fastest on every scene measured
+    if (wavefront || streamed) {
+        // Device workspace (wavefront: 72 B of path state per pixel; streamed: 12 B per pixel and sample of a 64-spp chunk),
+        // cached on the scene handle per device and grown on demand.  One such render at a time per scene handle and
+        // device (the workspace is shared); the megakernel has no such restriction.
         int dev = 0;
         TRT_HIP(hipGetDevice(&dev));
-        const size_t need = wavefront_workspace_bytes(cam->width, rows);
+        const size_t need = wavefront ? wavefront_workspace_bytes(cam->width, rows) : streamed_workspace_bytes(cam->width, rows);
         void* ws = nullptr;
         {
             std::lock_guard<std::mutex> lock(s->mu);
@@ -154,6 +156,10 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
                 w.bytes = need;
             }
             ws = w.ptr;
+        }
+        if (streamed) {
+            TRT_HIP(launch_streamed(sc, cd, ra, ws, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));
+            return TRT_OK;
         }
         uint32_t serve_min = 0;
         if (const char* e = getenv("TRT_WF_SERVE_MIN")) serve_min = (uint32_t)atoi(e);
@@ -421,6 +427,8 @@ int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_s
     return TRT_OK;
 #undef TRT_HIP_C
 }
+
+uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows) { return streamed_chunk_spp(width, rows); }
 
 // ---- Imager finalisation ----
 int trt_tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* rgb) {

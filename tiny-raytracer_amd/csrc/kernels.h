@@ -69,6 +69,12 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
 hipError_t launch_pooled(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
                          unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream);
 
+// Streamed backend (streamed.hip): samples are work items; radiances go to an HBM buffer and are folded in order.
+uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows);   // samples per pixel per sample/fold launch pair (bounds the radiance buffer)
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows);
+hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
+                           unsigned long long* d_counters, bool stats, hipStream_t stream);
+
 // Sampler plug-in form: n caller-supplied rays.
 hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out,
                                const RenderArgs& ra, unsigned long long* d_counters, bool stats, hipStream_t stream);

@@ -1,0 +1,223 @@
+// streamed.hip — "streamed" backend (TRT_BACKEND_STREAMED), written for gfx950 (CDNA4) only.
+//
+// The megakernel binds a lane to one pixel for a whole launch.  That ties the length of a launch to the most
+// expensive pixel (in the Cornell box the per-pixel cost varies ~2x across the image) and to the longest of a
+// wave's 64 sample chains; both hurt exactly when the launch is small: a short progressive pass, or one of 8 GPUs'
+// share of the frame (2048 workgroups for 1792 resident ones: measured 16.5 Gray/s per GPU against 25.0 on the
+// whole frame).  Here a SAMPLE, not a pixel, is the unit of work:
+//
+//  * SAMPLE kernel: a persistent grid of waves pulls batches (one 8x8 pixel tile x 8 consecutive samples = 512 items,
+//    ~3.6 k rays: small against a wave's share even of one GPU's eighth of a frame) from a global counter, one
+//    returning atomic per batch (<10 per us, the counter word saturates near 88); inside a wave every lane takes the next item of
+//    the batch whenever its path ends (ballot + mbcnt ranks on a wave-uniform cursor, no atomics), so no lane waits
+//    for a neighbour's longer chain or a more expensive pixel.  The finished sample's radiance (12 B) goes to an HBM
+//    buffer laid out [sample][pixel].
+//  * FOLD kernel: one lane per pixel adds that pixel's radiances in sample order,
+//    `pixels[idx] += color * (1/spp)` (imager.rs:50): the same sequence of f32 additions as the reference, so the
+//    frame is bit-identical to the megakernel's and the oracle's whatever lane computed which sample.
+//
+// Cost: 12 B written + 12 B read per sample (a sample is ~7 rays, ~4.6 KB algorithmic), i.e. <1 % extra traffic, and
+// two launches per chunk of samples (sized to a ~4 GB radiance buffer) instead of one.  The primary-ray stock of kernels.hip is kept (items are taken ahead).
+#include <stdlib.h>
+
+#include "kernels.h"
+#include "rt_path.h"
+
+namespace trt {
+
+constexpr uint32_t kBatchSpp = 8;            // samples per pixel in one batch
+
+TRT_DEV uint32_t st_rank(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+template <int MODE, bool STATS, int MINW = 1, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev scd, CameraDev cam, RenderArgs ra,
+                                                                             float* __restrict__ colors,
+                                                                             uint32_t* __restrict__ batch_counter,
+                                                                             unsigned long long* __restrict__ counters,
+                                                                             uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches) {
+    stage_scene_to_lds<MODE>(scd);
+    const SceneAcc<MODE> sc{scd.blob, scd.L};
+    const uint32_t lane = threadIdx.x & 63u;
+    const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
+    const uint32_t n_spp = ra.sample_end - ra.sample_begin;
+    const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
+
+    // wave-uniform work cursor
+    uint32_t tile_x0 = 0, tile_row0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // cursor == items_per_batch: batch used up
+    bool exhausted = false;
+
+    Path p;
+    p.remain = 0u;
+    bool has_path = false, stocked = false;
+    unsigned long long out_idx = 0, stock_idx = 0;                        // (sample - sample_begin) * n_pixels + pixel
+    Ray stock_ray;
+    Rng stock_rng;
+    uint32_t n_samples = 0, n_rays = 0;
+    Counters<STATS> ctr;
+
+    for (;;) {
+        // ---- take items ahead: whenever a lane has neither a path nor a stocked ray, every lane without stock takes one ----
+        if (!exhausted && __builtin_amdgcn_ballot_w64(!has_path && !stocked) != 0ull) {
+            if (cursor >= items_per_batch) {
+                uint32_t b = 0;
+                if (lane == 0u) b = atomicAdd(batch_counter, 1u);
+                b = __builtin_amdgcn_readfirstlane(b);
+                if (b >= n_batches) {
+                    exhausted = true;
+                } else {
+                    const uint32_t tile = b % n_tiles;                                // consecutive batches: neighbouring tiles, same samples
+                    ds0 = (b / n_tiles) * kBatchSpp;
+                    tile_x0 = (tile % tiles_x) * 8u;
+                    tile_row0 = (tile / tiles_x) * 8u;
+                    items_per_batch = 64u * (n_spp - ds0 < kBatchSpp ? n_spp - ds0 : kBatchSpp);
+                    cursor = 0;
+                }
+            }
+            if (!exhausted) {
+                const uint64_t want = __builtin_amdgcn_ballot_w64(!stocked);
+                const uint32_t item = cursor + st_rank(want);
+                cursor += (uint32_t)__builtin_popcountll(want);
+                if (!stocked && item < items_per_batch) {
+                    const uint32_t l = item & 63u, ds = ds0 + (item >> 6);         // neighbouring items = neighbouring pixels, same sample
+                    const uint32_t x = tile_x0 + (l & 7u), row = tile_row0 + (l >> 3);
+                    if (x < cam.width && row < ra.rows_local) {
+                        if constexpr (STATS) { if (first_active_lane()) ctr.w_gen++; }
+                        const uint32_t y = image_row(ra, row);
+                        stock_rng = rng_seed(ra.seed_key, y * cam.width + x, ra.sample_begin + ds);
+                        stock_ray = primary_ray(cam, x, y, stock_rng);
+                        stock_idx = (unsigned long long)ds * n_pixels + (unsigned long long)row * cam.width + x;
+                        stocked = true;
+                    }
+                }
+            }
+        }
+        if (!has_path && stocked) {                                               // cpu.rs:42-45
+            p.ray = stock_ray;
+            p.rng = stock_rng;
+            p.color = v3(0.0f, 0.0f, 0.0f);
+            p.atten = v3(1.0f, 1.0f, 1.0f);
+            p.remain = ra.max_bounces;
+            out_idx = stock_idx;
+            has_path = true;
+            stocked = false;
+            n_samples++;
+        }
+        if (__builtin_amdgcn_ballot_w64(has_path) == 0ull) {
+            if (exhausted) break;
+            continue;                                                             // a batch of off-image items: fetch the next
+        }
+        if (has_path) {
+            if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
+            n_rays++;
+            float t;
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
+            if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
+                float* c = colors + 3ull * out_idx;
+                c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                has_path = false;
+            }
+        }
+    }
+    flush_counters<STATS>(counters, n_samples, n_rays, ctr);
+}
+
+// pixels[idx] += color * (1/spp), samples in order (imager.rs:35,50)
+__global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restrict__ colors, float* __restrict__ accum,
+                                                          unsigned long long n_pixels, uint32_t n_spp, float inv_spp,
+                                                          uint32_t accumulate) {
+    const unsigned long long pix = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= n_pixels) return;
+    float* out = accum + 3ull * pix;
+    V3 acc = v3(0.0f, 0.0f, 0.0f);
+    if (accumulate) acc = v3(out[0], out[1], out[2]);
+    for (uint32_t s = 0; s < n_spp; s++) {
+        const float* c = colors + 3ull * ((unsigned long long)s * n_pixels + pix);
+        acc = acc + v3(c[0], c[1], c[2]) * inv_spp;
+    }
+    out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
+}
+
+// Samples per pixel per sample/fold launch pair: as many as keep the radiance buffer near 4 GB (16..256).
+uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows) {
+    const unsigned long long px = (unsigned long long)width * rows;
+    const unsigned long long fit = px ? (4ull << 30) / (px * 12ull) : 256ull;
+    uint32_t c = 16;
+    while (c < 256u && 2ull * c <= fit) c *= 2u;                                  // power of two in 16..256
+    return c;
+}
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows) {
+    return (size_t)width * rows * streamed_chunk_spp(width, rows) * 3 * sizeof(float) + 256;      // radiance buffer + batch counter
+}
+
+hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra_all, void* workspace, float* d_accum,
+                           unsigned long long* d_counters, bool stats, hipStream_t stream) {
+    if (ra_all.rows_local == 0 || cam.width == 0) return hipSuccess;
+    const unsigned long long n_pixels = (unsigned long long)ra_all.rows_local * cam.width;
+    float* colors = static_cast<float*>(workspace);
+    const uint32_t chunk = streamed_chunk_spp(cam.width, ra_all.rows_local);
+    uint32_t* batch_counter = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (size_t)n_pixels * chunk * 3 * sizeof(float));
+    const uint32_t tiles_x = (cam.width + 7u) / 8u, tiles_y = (ra_all.rows_local + 7u) / 8u;
+    const uint32_t n_tiles = tiles_x * tiles_y;
+    int dev = 0, cus = 256;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const size_t lds_bytes = scene_lds_bytes(sc.L);
+    const int mode = scene_mode(sc.L);
+    // waves per SIMD / lanes per workgroup as in kernels.hip: 7 waves for small LDS copies, 512-lane workgroups sharing a
+    // big LDS copy between 8 waves, no cap for scenes read from global memory
+    const int threads = (mode == MODE_LDS && sc.L.hot_bytes > 20u * 1024u) ? 512 : 256;
+    int w = mode == MODE_LDS ? (threads == 512 ? 6 : 7) : 5;
+    if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
+    if (w < 5) w = 5;
+    if (threads == 512 && w > 6) w = 6;
+    uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
+    if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
+    const uint32_t resident = (uint32_t)cus * wg_per_cu;
+    const uint32_t waves_per_wg = (uint32_t)threads / 64u;
+    bool first = true;
+    for (uint32_t s0 = ra_all.sample_begin; s0 < ra_all.sample_end; s0 += chunk) {
+        RenderArgs ra = ra_all;
+        ra.sample_begin = s0;
+        ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;
+        const uint32_t n_batches = n_tiles * ((ra.sample_end - ra.sample_begin + kBatchSpp - 1u) / kBatchSpp);
+        uint32_t grid_x = resident;
+        const uint32_t max_useful = (n_batches + waves_per_wg - 1u) / waves_per_wg;   // one batch per wave at least
+        if (grid_x > max_useful) grid_x = max_useful ? max_useful : 1u;
+        const dim3 grid(grid_x), block((uint32_t)threads);
+        e = hipMemsetAsync(batch_counter, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+        auto go = [&](auto kernel) -> hipError_t {
+            if (lds_bytes > 48u * 1024u) {
+                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+                if (e2 != hipSuccess) return e2;
+            }
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches);
+            return hipGetLastError();
+        };
+        switch (mode) {
+            case MODE_LDS:
+                if (threads == 512) {
+                    if (w >= 6) e = stats ? go(stream_sample_kernel<MODE_LDS, true, 6, 512>) : go(stream_sample_kernel<MODE_LDS, false, 6, 512>);
+                    else e = stats ? go(stream_sample_kernel<MODE_LDS, true, 5, 512>) : go(stream_sample_kernel<MODE_LDS, false, 5, 512>);
+                } else if (w >= 7) e = stats ? go(stream_sample_kernel<MODE_LDS, true, 7>) : go(stream_sample_kernel<MODE_LDS, false, 7>);
+                else if (w == 6) e = stats ? go(stream_sample_kernel<MODE_LDS, true, 6>) : go(stream_sample_kernel<MODE_LDS, false, 6>);
+                else e = stats ? go(stream_sample_kernel<MODE_LDS, true, 5>) : go(stream_sample_kernel<MODE_LDS, false, 5>);
+                break;
+            case MODE_HYBRID: e = stats ? go(stream_sample_kernel<MODE_HYBRID, true>) : go(stream_sample_kernel<MODE_HYBRID, false>); break;
+            default: e = stats ? go(stream_sample_kernel<MODE_GLOBAL, true>) : go(stream_sample_kernel<MODE_GLOBAL, false>); break;
+        }
+        if (e != hipSuccess) return e;
+        const uint32_t fold_blocks = (uint32_t)((n_pixels + 255ull) / 256ull);
+        hipLaunchKernelGGL(stream_fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, colors, d_accum, n_pixels, ra.sample_end - ra.sample_begin,
+                           ra_all.inv_spp, (first && !ra_all.accumulate) ? 0u : 1u);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        first = false;
+    }
+    return hipSuccess;
+}
+
+}  // namespace trt
