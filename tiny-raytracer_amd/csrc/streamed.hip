@@ -51,7 +51,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     Path p;
     p.remain = 0u;
     bool has_path = false, stocked = false;
-    unsigned long long out_idx = 0, stock_idx = 0;                        // (sample - sample_begin) * n_pixels + pixel
+    uint32_t out_idx = 0, stock_idx = 0;                                  // (sample - sample_begin) * n_pixels + pixel: < 2^32 (see streamed_chunk_spp)
     Ray stock_ray;
     Rng stock_rng;
     uint32_t n_samples = 0, n_rays = 0;
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                         const uint32_t y = image_row(ra, row);
                         stock_rng = rng_seed(ra.seed_key, y * cam.width + x, ra.sample_begin + ds);
                         stock_ray = primary_ray(cam, x, y, stock_rng);
-                        stock_idx = (unsigned long long)ds * n_pixels + (unsigned long long)row * cam.width + x;
+                        stock_idx = ds * (uint32_t)n_pixels + row * cam.width + x;
                         stocked = true;
                     }
                 }
@@ -145,6 +145,7 @@ uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows) {
     const unsigned long long fit = px ? (4ull << 30) / (px * 12ull) : 256ull;
     uint32_t c = 16;
     while (c < 256u && 2ull * c <= fit) c *= 2u;                                  // power of two in 16..256
+    while (c > 1u && px * c >= (1ull << 32)) c /= 2u;                             // radiance slots are indexed with 32 bits
     return c;
 }
 size_t streamed_workspace_bytes(uint32_t width, uint32_t rows) {
