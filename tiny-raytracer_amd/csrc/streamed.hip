@@ -36,7 +36,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                                                                              float* __restrict__ colors,
                                                                              uint32_t* __restrict__ batch_counter,
                                                                              unsigned long long* __restrict__ counters,
-                                                                             uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches) {
+                                                                             uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp) {
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
     const uint32_t lane = threadIdx.x & 63u;
@@ -68,10 +68,10 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                     exhausted = true;
                 } else {
                     const uint32_t tile = b % n_tiles;                                // consecutive batches: neighbouring tiles, same samples
-                    ds0 = (b / n_tiles) * kBatchSpp;
+                    ds0 = (b / n_tiles) * batch_spp;
                     tile_x0 = (tile % tiles_x) * 8u;
                     tile_row0 = (tile / tiles_x) * 8u;
-                    items_per_batch = 64u * (n_spp - ds0 < kBatchSpp ? n_spp - ds0 : kBatchSpp);
+                    items_per_batch = 64u * (n_spp - ds0 < batch_spp ? n_spp - ds0 : batch_spp);
                     cursor = 0;
                 }
             }
@@ -183,7 +183,9 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         RenderArgs ra = ra_all;
         ra.sample_begin = s0;
         ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;
-        const uint32_t n_batches = n_tiles * ((ra.sample_end - ra.sample_begin + kBatchSpp - 1u) / kBatchSpp);
+        uint32_t batch_spp = kBatchSpp;
+        if (const char* env = getenv("TRT_STREAM_BATCH_SPP")) batch_spp = (uint32_t)atoi(env) ? (uint32_t)atoi(env) : kBatchSpp;
+        const uint32_t n_batches = n_tiles * ((ra.sample_end - ra.sample_begin + batch_spp - 1u) / batch_spp);
         uint32_t grid_x = resident;
         const uint32_t max_useful = (n_batches + waves_per_wg - 1u) / waves_per_wg;   // one batch per wave at least
         if (grid_x > max_useful) grid_x = max_useful ? max_useful : 1u;
@@ -195,7 +197,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                 if (e2 != hipSuccess) return e2;
             }
-            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches);
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches, batch_spp);
             return hipGetLastError();
         };
         switch (mode) {
