@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=256)
-    ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront", "pooled", "streamed"],
+    ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront", "streamed"],
                     help="auto = the library's default (streamed)")
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
@@ -124,9 +124,9 @@ def main():
     total_spp = 4096
     if args.backend == "auto":
         args.backend = "streamed"
-    backend = {"wavefront": trt.BACKEND_WAVEFRONT, "pooled": trt.BACKEND_POOLED, "streamed": trt.BACKEND_STREAMED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
+    backend = {"wavefront": trt.BACKEND_WAVEFRONT, "streamed": trt.BACKEND_STREAMED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
     renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1, backend=backend)
-    kernel_name = {"wavefront": "trt::wavefront_kernel", "pooled": "trt::pooled_kernel", "streamed": "trt::stream_sample_kernel"}.get(args.backend, "trt::megakernel")
+    kernel_name = {"wavefront": "trt::wavefront_kernel", "streamed": "trt::stream_sample_kernel"}.get(args.backend, "trt::megakernel")
 
     lay = tiles.band_layout(H, world_size, rank)
     band = dict(band_rows=lay["band_rows"], band_stride=lay["band_stride"], band_offset=lay["band_offset"],

@@ -115,8 +115,7 @@ enum trt_backend {
     TRT_BACKEND_WAVEFRONT = 1,    /* workgroup-resident wavefront: path state SoA in HBM, ray queues in LDS,
                                      generate / extend / sort-by-material / shade as phases of one persistent kernel */
     TRT_BACKEND_AUTO = 2,         /* the fastest measured backend (currently TRT_BACKEND_STREAMED for every scene) */
-    TRT_BACKEND_POOLED = 3,       /* megakernel with two pixels per lane whose rays are traced from a per-wave pool in LDS */
-    TRT_BACKEND_STREAMED = 4      /* samples as work items pulled by persistent waves; radiances folded per pixel in sample order */
+    TRT_BACKEND_STREAMED = 3      /* samples as work items pulled by persistent waves; radiances folded per pixel in sample order */
 };
 typedef struct {
     uint32_t samples_per_pixel;   /* Renderer::samples_per_pixel: fixes the 1/spp scale (imager.rs:35) */

@@ -5,7 +5,7 @@ import pytest
 from test_gpu_parity import STAT_KEYS, assert_bit_equal
 
 pytestmark = pytest.mark.gpu
-STREAMED = 4
+STREAMED = 3
 
 
 def render(trt, desc, spp, depth, seed=1, stats=True, **over):

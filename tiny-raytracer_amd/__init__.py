@@ -4,7 +4,7 @@ package fails if that library is not built.  The directory name has a hyphen, so
 importlib.import_module("tiny-raytracer_amd") or through the top-level alias module `tinyrt_amd`.
 """
 from . import scenes  # noqa: F401
-from ._lib import (BACKEND_AUTO, BACKEND_MEGAKERNEL, BACKEND_POOLED, BACKEND_STREAMED, BACKEND_WAVEFRONT, DIELECTRIC, LAMBERTIAN, LIGHT, METAL, CameraPOD,  # noqa: F401
+from ._lib import (BACKEND_AUTO, BACKEND_MEGAKERNEL, BACKEND_STREAMED, BACKEND_WAVEFRONT, DIELECTRIC, LAMBERTIAN, LIGHT, METAL, CameraPOD,  # noqa: F401
                    Material, Ray, RenderParams, SampledColor, SamplePoint, Stats, TinyRTError, Vec3, lib)
 from .api import (Camera, Dielectric, Image, Lambertian, Light, Metal, Quad, Renderer, Scene, Sphere, World,  # noqa: F401
                   sample_batch)

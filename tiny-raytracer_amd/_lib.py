@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 TRT_OK = 0
 ERR_INVALID_ARG, ERR_DUPLICATE, ERR_NOT_FOUND, ERR_HIP, ERR_NO_DEVICE, ERR_OOM = -1, -2, -3, -4, -5, -6
 LAMBERTIAN, METAL, DIELECTRIC, LIGHT = 0, 1, 2, 3
-BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, BACKEND_AUTO, BACKEND_POOLED, BACKEND_STREAMED = 0, 1, 2, 3, 4
+BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, BACKEND_AUTO, BACKEND_STREAMED = 0, 1, 2, 3
 
 
 class Vec3(C.Structure):

@@ -28,6 +28,7 @@ struct RenderArgs {
     uint32_t band_rows, band_stride, band_offset;   // local row -> image row (tinyrt.h)
     uint32_t rows_local;
     uint32_t xcd_aware;          // 1: remap workgroups so that each XCD renders a contiguous image region
+    uint32_t leaf_serve;         // box loop leaves for the primitive tests when this many lanes of the wave wait on a leaf
     uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
 };
 
@@ -64,10 +65,6 @@ struct WfState {
 size_t wavefront_workspace_bytes(uint32_t width, uint32_t rows);
 hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
                             unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream);
-
-// Pooled megakernel (pooled.hip): two pixels per lane, rays traced from a per-wave pool in LDS.
-hipError_t launch_pooled(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
-                         unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream);
 
 // Streamed backend (streamed.hip): samples are work items; radiances go to an HBM buffer and are folded in order.
 uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows);   // samples per pixel per sample/fold launch pair (bounds the radiance buffer)

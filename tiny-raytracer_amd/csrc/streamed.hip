@@ -112,7 +112,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr);
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_serve);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;

@@ -11,7 +11,7 @@ for n in (1, 2, 4, 8):
     lay = tiles.band_layout(2048, n, 0)
     band = dict(band_rows=lay["band_rows"], band_stride=lay["band_stride"], band_offset=lay["band_offset"], rows_local=lay["rows_local"]) if n > 1 else {}
     acc = torch.zeros((lay["rows_local"], 2048, 3), device=dev); ctr = torch.zeros(16, dtype=torch.int64, device=dev)
-    for name, backend in (("megakernel", 0), ("streamed", 4)):
+    for name, backend in (("megakernel", 0), ("streamed", 3)):
         r = trt.Renderer(4096, 1, 50, False, desc["background"], backend=backend)
         res = []
         for rep in range(3):

@@ -11,7 +11,7 @@ trt = importlib.import_module("tiny-raytracer_amd")
 
 CASES = [("cornell", lambda: trt.scenes.cornell(1024, 1024), 64), ("random_spheres", lambda: trt.scenes.random_spheres(960, 540), 64),
          ("sphere_grid100k", lambda: trt.scenes.sphere_grid(100000, 960, 540), 8)]
-BACKEND = int(os.environ.get("DIAG_BACKEND", "0"))
+BACKEND = int(os.environ.get("DIAG_BACKEND", "3"))
 if len(sys.argv) > 1:
     CASES = [c for c in CASES if c[0] in sys.argv[1:]]
 for name, mk, spp in CASES:
