@@ -133,7 +133,7 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
     if (rc != TRT_OK) return rc;
     CameraDev cd;
     to_camera_dev(*cam, cd);
-    if (!getenv("TRT_LEAF_SERVE")) ra.leaf_serve = sc.L.n_spheres > sc.L.n_quads ? 8u : 64u;   // rt_path.h closest_hit: cheap vs expensive primitive tests
+    if (!getenv("TRT_LEAF_SERVE")) ra.leaf_serve = sc.L.n_spheres > sc.L.n_quads ? 6u : 64u;   // rt_path.h closest_hit: cheap vs expensive primitive tests
     const size_t bytes = (size_t)rows * cam->width * 3 * sizeof(float);
     if (rows == 0 || ra.sample_begin == ra.sample_end || ra.max_bounces == 0) {
         // nothing to trace: a path with no bounce budget returns colour 0 (cpu.rs:43-47,64)
