@@ -111,3 +111,32 @@ def test_full_size_properties_cornell_2048_and_device_buffers(trt):
     band = r.render(pcam, pw, band_rows=16, band_stride=8, band_offset=3, rows_local=256).data
     rows = [((q // 16) * 8 + 3) * 16 + q % 16 for q in range(256)]
     assert_bit_equal(band, full[rows], "streamed band 3 of 8")
+
+
+def test_frames_match_the_reference_renders_statistically(trt):
+    """The product's frames against the PNGs the reference ships (same scene, spp, depth and background as the
+    reference source records; tests/golden/reference_png_blocks.json): block means of the quantised frame agree.
+    (The oracle passes the same check on CPU; this one goes GPU -> tonemap -> PNG statistics directly.)"""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_png_blocks.json")) as f:
+        fx = json.load(f)
+
+    def lin_blocks(u8, block):
+        lin = ((u8.astype(np.float64) + 0.5) / 255.0) ** 2.2
+        h, w, _ = u8.shape
+        bh, bw = h // block, w // block
+        return lin[: bh * block, : bw * block].reshape(bh, block, bw, block, 3).mean(axis=(1, 3))
+
+    cases = [("cornell", trt.scenes.cornell(300, 300), 300, 20, 0.985), ("quad_test", trt.scenes.quad_test(), 10, 10, 0.999),
+             ("render_test", trt.scenes.dummy_spheres("renderer"), 3, 10, 0.998)]
+    for key, desc, spp, depth, min_corr in cases:
+        f = fx[key]
+        ref = np.array(f["mean"])
+        ok = ~np.array(f["saturated"]).astype(bool)
+        pw, pcam = trt.world_from_description(desc)
+        img = trt.Renderer(spp, 8, depth, False, desc["background"], seed=21).render(pcam, pw)     # the reference's own settings
+        mine = lin_blocks(img.to_u8(), f["block"])
+        assert abs(mine[ok].mean() / ref[ok].mean() - 1.0) < 0.03, key
+        assert np.corrcoef(mine[ok].ravel(), ref[ok].ravel())[0, 1] > min_corr, key
