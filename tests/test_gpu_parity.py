@@ -5,6 +5,7 @@ pixel's samples in order, every f32 operation is the reference's, so any differi
 traversal counters must equal the oracle's too: the kernel visits exactly the reference's node sequence."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -38,9 +39,18 @@ def render_both(trt, orc, desc, spp, depth, seed=1, nthreads=8, stats=True, **ov
         counted = r.render(pcam, pw, collect_stats=True, **over)
         assert_bit_equal(counted.data, img.data, "counting kernel (reference tree) vs production kernel (culling tree)")
         gst = r.last_stats
-        # counting kernel on the culling tree: identical primitive tests and hits, fewer (or equal) box tests
+        # counting kernel on the culling tree: exactly the reference's primitive tests and hits, whatever the number of
+        # postponed-leaf slots (default 4); with one slot (plain while-while) also fewer (or equal) box tests
         own = r.render(pcam, pw, collect_stats=2, **over)
         assert_bit_equal(own.data, img.data, "counting kernel on the culling tree")
+        for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
+            assert r.last_stats[k] == gst[k], k
+        os.environ["TRT_LEAF_SLOTS"] = "1"
+        try:
+            plain = r.render(pcam, pw, collect_stats=2, **over)
+        finally:
+            del os.environ["TRT_LEAF_SLOTS"]
+        assert_bit_equal(plain.data, img.data, "counting kernel on the culling tree, one leaf slot")
         for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
             assert r.last_stats[k] == gst[k], k
         assert r.last_stats["node_tests"] <= gst["node_tests"]

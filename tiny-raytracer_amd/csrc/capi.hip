@@ -7,6 +7,7 @@
 // compute entry point fails with TRT_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -114,8 +115,8 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
         ra.band_rows = p->band_rows; ra.band_stride = p->band_stride; ra.band_offset = p->band_offset;
     }
     ra.rows_local = rows;
-    ra.leaf_serve = 64u;                                   // scene-dependent default: set in enqueue_render
-    if (const char* e = getenv("TRT_LEAF_SERVE")) ra.leaf_serve = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : 64u;
+    ra.leaf_slots = 4u;                                    // rt_path.h walk_fast; scheduling only, any value renders the same frame
+    if (const char* e = getenv("TRT_LEAF_SLOTS")) ra.leaf_slots = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : 4u;
     ra.xcd_aware = getenv("TRT_XCD_REMAP") ? 1u : 0u;   // off: contiguous image regions per XCD measured 2x slower (load imbalance)
     ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;
@@ -133,7 +134,6 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
     if (rc != TRT_OK) return rc;
     CameraDev cd;
     to_camera_dev(*cam, cd);
-    if (!getenv("TRT_LEAF_SERVE")) ra.leaf_serve = sc.L.n_spheres > sc.L.n_quads ? 6u : 64u;   // rt_path.h closest_hit: cheap vs expensive primitive tests
     const size_t bytes = (size_t)rows * cam->width * 3 * sizeof(float);
     if (rows == 0 || ra.sample_begin == ra.sample_end || ra.max_bounces == 0) {
         // nothing to trace: a path with no bounce budget returns colour 0 (cpu.rs:43-47,64)
@@ -393,7 +393,7 @@ int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_s
     ra.max_bounces = max_bounces;
     ra.seed_key = rng_seed_key(seed);
     ra.ref_tree = 1u;                             // the batch form always counts: walk the reference tree
-    ra.leaf_serve = 64u;
+    ra.leaf_slots = 1u;
     trt_sample_point* d_in = nullptr;
     trt_sampled_color* d_out = nullptr;
     unsigned long long* d_ctr = nullptr;

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(THREADS, MINW) void megakernel(SceneDev scd, Camera
             }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_serve);
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 acc = acc + p.color * ra.inv_spp;                                   // imager.rs:50
                 s++;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void sample_batch_kernel(SceneDev scd, const t
         if (alive) {
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_serve);
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) alive = false;
         }
     }

@@ -229,6 +229,20 @@ TRT_DEV bool slab_fast(float4 na, float4 nb, V3 o, V3 inv, float start, float en
     return !(end <= start);
 }
 
+// slab_fast that also returns the interval's start, max(start, nearest entry): with it the same box can be re-tested
+// against a smaller `end` later by one comparison (pass' = pass && end' > start_out; see rt_path.h walk_fast).
+TRT_DEV bool slab_fast_entry(float4 na, float4 nb, V3 o, V3 inv, float start, float end, float& start_out) {
+    float x0 = (na.x - o.x) * inv.x, x1 = (na.w - o.x) * inv.x;
+    float y0 = (na.y - o.y) * inv.y, y1 = (nb.x - o.y) * inv.y;
+    float z0 = (na.z - o.z) * inv.z, z1 = (nb.y - o.z) * inv.z;
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+    start = __builtin_fmaxf(start, tn);
+    end = __builtin_fminf(end, tf);
+    start_out = start;
+    return !(end <= start);
+}
+
 TRT_DEV bool finite_f(float v) { return __builtin_fabsf(v) < __builtin_inff(); }
 
 // ------------------------------------------------------------------------------------------------

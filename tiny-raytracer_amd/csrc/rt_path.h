@@ -161,74 +161,91 @@ TRT_DEV void trav_leaf(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, uint3
     }
 }
 
-// Whole walk for one lane ("while-while": the lanes of a wave run box tests together, then
-// primitive tests together).  Returns the primitive reference (PRIM_NONE on a miss) and its t.
-// The common case (finite ray, culling tree, min/max slab test) gets a loop of its own so that
-// the rare cases' branches and loads stay out of the hot loop.
+// The rare walks: reference tree (counting kernels) and rays whose slab arithmetic needs the reference's
+// compare-and-assign form.  Runs the walk `tr` to its end.
+template <int MODE, bool STATS>
+TRT_DEV void closest_hit_ref(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
+    for (;;) {
+        uint32_t leaf = PRIM_NONE;
+        while (tr.i < tr.n) {
+            leaf = trav_box_step<MODE, STATS>(sc, ray, tr, ctr);
+            if (leaf != PRIM_NONE) break;
+        }
+        if (leaf == PRIM_NONE) break;
+        if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+        trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr);
+    }
+}
+
+// The common walk (finite ray, culling tree, min/max slab test): speculative "while-while" (Aila & Laine 2009).  The lanes
+// of a wave step boxes together, then run primitive tests together; a lane that stands on a leaf whose box it hit
+// remembers the leaf and keeps stepping boxes until it holds SLOTS of them (or its walk is over); then its primitive
+// tests run, in walk order.  With one slot the wave leaves the box loop at every leaf any lane finds and a lane mostly
+// waits for its neighbours' longer searches (Cornell: 31 % of the lanes busy in a box step); with four it leaves a
+// quarter as often.
+//
+// Scheduling only - a lane runs the reference's primitive tests, no more and no fewer, and gets the same hit:
+//  * the boxes stepped while tests are postponed see the t_best of before those tests, a LARGER interval, so no leaf
+//    the reference reaches is skipped;
+//  * a postponed leaf is tested only if its box still passes with the CURRENT t_best.  No arithmetic is needed for
+//    that: slab_fast passes iff min(t_best, t_far) > start with start = max(t_min, t_near), it did pass with the
+//    older, larger t_best (so t_far > start), hence it passes now iff t_best > start - one comparison with the
+//    `start` kept beside the postponed leaf.  That is bit for bit the reference's box test at the moment the
+//    reference stands on this leaf (same operands, same t_best), and the leaf's ancestors pass whenever the leaf does
+//    (DESIGN.md 4.1), so the primitive is tested exactly when the reference tests it.
+template <int MODE, bool STATS, int SLOTS>
+TRT_DEV void walk_fast(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
+    const uint32_t n = sc.L.n_cull_nodes;
+    for (;;) {
+        uint32_t pend[SLOTS];
+        float entry[SLOTS];
+#pragma unroll
+        for (int k = 0; k < SLOTS; k++) { pend[k] = PRIM_NONE; entry[k] = 0.0f; }
+        while (tr.i < n && pend[SLOTS - 1] == PRIM_NONE) {
+            float4 na, nb;
+            sc.node(tr.i, na, nb);
+            if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+            float start;
+            const bool pass = slab_fast_entry(na, nb, ray.o, tr.inv, kTMin, tr.t_best, start);
+            const uint32_t link = __float_as_uint(nb.w);
+            const bool inner = (link & NODE_INNER_BIT) != 0u;
+            tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);     // descend, or skip (a leaf's skip is its successor)
+            if (pass && !inner) {                                                          // into the first free slot
+                bool placed = false;
+#pragma unroll
+                for (int k = 0; k < SLOTS; k++) {
+                    const bool here = !placed && pend[k] == PRIM_NONE;
+                    pend[k] = here ? link : pend[k];
+                    entry[k] = here ? start : entry[k];
+                    placed = placed || here;
+                }
+            }
+        }
+        if (pend[0] == PRIM_NONE) break;
+        while (pend[0] != PRIM_NONE) {
+            if (tr.t_best > entry[0]) {                                                    // the leaf's box test with the current t_best
+                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+                trav_leaf<MODE, STATS>(sc, ray, tr, pend[0], ctr);
+            }
+#pragma unroll
+            for (int k = 0; k + 1 < SLOTS; k++) { pend[k] = pend[k + 1]; entry[k] = entry[k + 1]; }
+            pend[SLOTS - 1] = PRIM_NONE;
+        }
+    }
+}
+
+// Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  `leaf_slots`: 4 (default),
+// 2 or 1 (tuning and tests; wave-uniform).
 template <int MODE, bool STATS>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
-                             uint32_t leaf_serve = 64u) {
+                             uint32_t leaf_slots = 4u) {
     Trav tr = trav_begin(sc, ray, ref_tree);
     if (__builtin_expect(!tr.ref, 1)) {
-        const uint32_t n = sc.L.n_cull_nodes;
-        if (leaf_serve >= 64u) {
-            // plain while-while: box tests until every lane stands on a leaf whose box it hit (or ran off the end), then
-            // the primitive tests.  Best when the primitive test is expensive (quads: Cornell 28.8 vs 28.6 Gray/s).
-            for (;;) {
-                uint32_t leaf = PRIM_NONE;
-                while (tr.i < n) {
-                    float4 na, nb;
-                    sc.node(tr.i, na, nb);
-                    if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
-                    const bool pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
-                    const uint32_t link = __float_as_uint(nb.w);
-                    const bool inner = (link & NODE_INNER_BIT) != 0u;
-                    tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);
-                    if (pass && !inner) { leaf = link; break; }
-                }
-                if (leaf == PRIM_NONE) break;
-                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-                trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr);
-            }
-        } else {
-            // served while-while: the wave leaves the box loop as soon as `leaf_serve` lanes wait on a leaf, so they get
-            // their (cheap) primitive test and rejoin the box tests early.  Best for spheres (random-spheres 16.3 vs
-            // 14.9 Gray/s at leaf_serve = 8).  Scheduling only: every lane's walk is the same.
-            for (;;) {
-                uint32_t leaf = PRIM_NONE;
-                for (;;) {
-                    const bool in_box = leaf == PRIM_NONE && tr.i < n;
-                    if (__builtin_amdgcn_ballot_w64(in_box) == 0ull) break;
-                    if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(leaf != PRIM_NONE)) >= leaf_serve) break;
-                    if (in_box) {
-                        float4 na, nb;
-                        sc.node(tr.i, na, nb);
-                        if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
-                        const bool pass = slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best);
-                        const uint32_t link = __float_as_uint(nb.w);
-                        const bool inner = (link & NODE_INNER_BIT) != 0u;
-                        tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);
-                        if (pass && !inner) leaf = link;
-                    }
-                }
-                if (__builtin_amdgcn_ballot_w64(leaf != PRIM_NONE || tr.i < n) == 0ull) break;      // every lane's walk is over
-                if (leaf != PRIM_NONE) {
-                    if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-                    trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr);
-                }
-            }
-        }
+        if (leaf_slots >= 4u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
+        else if (leaf_slots >= 2u) walk_fast<MODE, STATS, 2>(sc, ray, tr, ctr);
+        else walk_fast<MODE, STATS, 1>(sc, ray, tr, ctr);
     } else {
-        for (;;) {
-            uint32_t leaf = PRIM_NONE;
-            while (tr.i < tr.n) {
-                leaf = trav_box_step<MODE, STATS>(sc, ray, tr, ctr);
-                if (leaf != PRIM_NONE) break;
-            }
-            if (leaf == PRIM_NONE) break;
-            if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-            trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr);
-        }
+        closest_hit_ref<MODE, STATS>(sc, ray, tr, ctr);
     }
     t_hit = tr.t_best;
     return tr.prim_best;

@@ -112,7 +112,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_serve);
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -137,6 +137,12 @@ __global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restric
         acc = acc + v3(c[0], c[1], c[2]) * inv_spp;
     }
     out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
+}
+
+// counting or plain variant at fixed scene mode / waves per SIMD / workgroup size
+template <int MODE, int MINW, int THREADS, typename Go>
+static hipError_t launch_pick(bool stats, Go&& go) {
+    return stats ? go(stream_sample_kernel<MODE, true, MINW, THREADS>) : go(stream_sample_kernel<MODE, false, MINW, THREADS>);
 }
 
 // Samples per pixel per sample/fold launch pair: as many as keep the radiance buffer near 4 GB (16..256).
@@ -203,14 +209,14 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         switch (mode) {
             case MODE_LDS:
                 if (threads == 512) {
-                    if (w >= 6) e = stats ? go(stream_sample_kernel<MODE_LDS, true, 6, 512>) : go(stream_sample_kernel<MODE_LDS, false, 6, 512>);
-                    else e = stats ? go(stream_sample_kernel<MODE_LDS, true, 5, 512>) : go(stream_sample_kernel<MODE_LDS, false, 5, 512>);
-                } else if (w >= 7) e = stats ? go(stream_sample_kernel<MODE_LDS, true, 7>) : go(stream_sample_kernel<MODE_LDS, false, 7>);
-                else if (w == 6) e = stats ? go(stream_sample_kernel<MODE_LDS, true, 6>) : go(stream_sample_kernel<MODE_LDS, false, 6>);
-                else e = stats ? go(stream_sample_kernel<MODE_LDS, true, 5>) : go(stream_sample_kernel<MODE_LDS, false, 5>);
+                    if (w >= 6) e = launch_pick<MODE_LDS, 6, 512>(stats, go);
+                    else e = launch_pick<MODE_LDS, 5, 512>(stats, go);
+                } else if (w >= 7) e = launch_pick<MODE_LDS, 7, 256>(stats, go);
+                else if (w == 6) e = launch_pick<MODE_LDS, 6, 256>(stats, go);
+                else e = launch_pick<MODE_LDS, 5, 256>(stats, go);
                 break;
-            case MODE_HYBRID: e = stats ? go(stream_sample_kernel<MODE_HYBRID, true>) : go(stream_sample_kernel<MODE_HYBRID, false>); break;
-            default: e = stats ? go(stream_sample_kernel<MODE_GLOBAL, true>) : go(stream_sample_kernel<MODE_GLOBAL, false>); break;
+            case MODE_HYBRID: e = launch_pick<MODE_HYBRID, 1, 256>(stats, go); break;
+            default: e = launch_pick<MODE_GLOBAL, 1, 256>(stats, go); break;
         }
         if (e != hipSuccess) return e;
         const uint32_t fold_blocks = (uint32_t)((n_pixels + 255ull) / 256ull);
