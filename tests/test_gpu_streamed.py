@@ -142,26 +142,30 @@ def test_frames_match_the_reference_renders_statistically(trt):
         assert np.corrcoef(mine[ok].ravel(), ref[ok].ravel())[0, 1] > min_corr, key
 
 
-def test_leaf_slots_are_scheduling_only(trt, monkeypatch):
-    """The postponed-leaf walk (rt_path.h walk_fast) must run exactly the reference's primitive tests: frames, ray counts
-    and primitive-test counters at 4 slots (default), 2 and 1 (plain while-while) are identical on a scene large
-    enough for grazing hits to occur (an earlier version that tested postponed leaves without re-checking their box
-    against the current t_best differed here in ~1e-7 of the rays, and only here)."""
-    desc = trt.scenes.random_spheres(960, 540)
+@pytest.mark.parametrize("scene", ["random_spheres", "cornell"])
+def test_leaf_slots_are_scheduling_only(trt, monkeypatch, scene):
+    """The postponed-leaf walk (rt_path.h walk_fast / walk_fast_lds) must run exactly the reference's primitive tests:
+    frames, ray counts and primitive-test counters are identical for 1 slot (plain while-while), 2, 4 (default) and 8,
+    with the slots in registers or in LDS, on scenes large enough for grazing hits to occur (an earlier version that
+    tested postponed leaves without re-checking their box against the current t_best differed on random-spheres in
+    ~1e-7 of the rays, and only there)."""
+    desc = trt.scenes.random_spheres(960, 540) if scene == "random_spheres" else trt.scenes.cornell(512, 512)
     pw, pcam = trt.world_from_description(desc)
     r = trt.Renderer(16, 1, 50, False, desc["background"], seed=5, backend=STREAMED)
     ref_img = ref_stats = None
-    for slots in ("1", "2", "4"):
+    for slots, lds in (("1", "0"), ("2", "0"), ("4", "0"), ("1", "2"), ("4", "2"), ("8", "2"), ("4", "1")):
         monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
+        monkeypatch.setenv("TRT_LDS_LEAF_STACK", lds)                               # 0 registers, 2 LDS, 1 LDS where it costs no occupancy
         img = r.render(pcam, pw, collect_stats=2)
         st = r.last_stats
         if ref_img is None:
             ref_img, ref_stats = img.data.copy(), dict(st)
             continue
-        assert np.array_equal(img.data.view(np.uint32), ref_img.view(np.uint32)), slots
+        assert np.array_equal(img.data.view(np.uint32), ref_img.view(np.uint32)), (slots, lds)
         for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
-            assert st[k] == ref_stats[k], (slots, k)
+            assert st[k] == ref_stats[k], (slots, lds, k)
     monkeypatch.delenv("TRT_LEAF_SLOTS")
-    plain = r.render(pcam, pw)                                                      # production (non-counting) kernel, default slots
+    monkeypatch.delenv("TRT_LDS_LEAF_STACK")
+    plain = r.render(pcam, pw)                                                      # production (non-counting) kernel, defaults
     assert np.array_equal(plain.data.view(np.uint32), ref_img.view(np.uint32))
     assert r.last_stats["rays"] == ref_stats["rays"]

@@ -28,6 +28,7 @@ struct RenderArgs {
     uint32_t band_rows, band_stride, band_offset;   // local row -> image row (tinyrt.h)
     uint32_t rows_local;
     uint32_t xcd_aware;          // 1: remap workgroups so that each XCD renders a contiguous image region
+    uint32_t lds_leaf_stack;     // streamed backend: keep the postponed leaves in LDS (rt_path.h walk_fast_lds) instead of registers: 0 no, 1 where it costs no occupancy, 2 always
     uint32_t leaf_slots;         // postponed-leaf slots per lane in the walk (rt_path.h walk_fast): 4, 2 or 1
     uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
 };

@@ -234,14 +234,54 @@ TRT_DEV void walk_fast(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Count
     }
 }
 
-// Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  `leaf_slots`: 4 (default),
-// 2 or 1 (tuning and tests; wave-uniform).
+// The same walk with the postponed leaves in LDS instead of registers: `stk` is this lane's slot 0, slot k lives at
+// stk[64 * k] (one 8-byte (leaf, start) pair per lane and slot, lane-contiguous: conflict-free ds_write_b64 /
+// ds_read_b64).  Putting a leaf aside costs one address, one LDS write and one add instead of the compare/select
+// chain over SLOTS registers (13 VALU instructions per box-step trip at 4 slots: the wave pays them whenever ANY lane
+// finds a leaf, which is nearly every trip), and the slots cost no VGPRs.  LDS operations of one wave complete in
+// order, so a lane reads back what it wrote without a barrier.
+template <int MODE, bool STATS>
+TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
+    const uint32_t n = sc.L.n_cull_nodes;
+    for (;;) {
+        uint32_t cnt = 0;
+        while (tr.i < n && cnt < slots) {
+            float4 na, nb;
+            sc.node(tr.i, na, nb);
+            if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+            float start;
+            const bool pass = slab_fast_entry(na, nb, ray.o, tr.inv, kTMin, tr.t_best, start);
+            const uint32_t link = __float_as_uint(nb.w);
+            const bool inner = (link & NODE_INNER_BIT) != 0u;
+            tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);     // descend, or skip (a leaf's skip is its successor)
+            if (pass && !inner) {
+                stk[64u * cnt] = make_float2(nb.w, start);
+                cnt++;
+            }
+        }
+        if (cnt == 0u) break;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const float2 e = stk[64u * k];
+            if (tr.t_best > e.y) {                                                         // the leaf's box test with the current t_best
+                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+                trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(e.x), ctr);
+            }
+        }
+    }
+}
+
+constexpr uint32_t kLdsLeafSlotsMax = 8;  // most slots per lane of the LDS leaf stack (8 bytes each)
+
+// Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  Postponed leaves go to
+// `lds_stack` (this lane's slot 0 of a `leaf_slots`-deep LDS stack) if the kernel has one, else into registers:
+// `leaf_slots` = 4 (default), 2 or 1 (tuning and tests; wave-uniform).
 template <int MODE, bool STATS>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
-                             uint32_t leaf_slots = 4u) {
+                             uint32_t leaf_slots = 4u, float2* lds_stack = nullptr) {
     Trav tr = trav_begin(sc, ray, ref_tree);
     if (__builtin_expect(!tr.ref, 1)) {
-        if (leaf_slots >= 4u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
+        if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
+        else if (leaf_slots >= 4u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
         else if (leaf_slots >= 2u) walk_fast<MODE, STATS, 2>(sc, ray, tr, ctr);
         else walk_fast<MODE, STATS, 1>(sc, ray, tr, ctr);
     } else {

@@ -43,6 +43,10 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
     const uint32_t n_spp = ra.sample_end - ra.sample_begin;
     const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
+    // postponed-leaf stack (rt_path.h walk_fast_lds): behind the scene copy, leaf_slots x 64 x 8 bytes per wave
+    float2* const leaf_stack = ra.lds_leaf_stack
+        ? reinterpret_cast<float2*>(reinterpret_cast<char*>(g_lds) + ((sc.lds_bytes() + 15u) & ~15u)) + (threadIdx.x >> 6) * (64u * ra.leaf_slots) + lane
+        : nullptr;
 
     // wave-uniform work cursor
     uint32_t tile_x0 = 0, tile_row0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // cursor == items_per_batch: batch used up
@@ -112,7 +116,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots);
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -171,7 +175,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const size_t lds_bytes = scene_lds_bytes(sc.L);
+    const size_t scene_bytes = scene_lds_bytes(sc.L);
     const int mode = scene_mode(sc.L);
     // waves per SIMD / lanes per workgroup as in kernels.hip: 7 waves for small LDS copies, 512-lane workgroups sharing a
     // big LDS copy between 8 waves, no cap for scenes read from global memory
@@ -181,12 +185,27 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     if (w < 5) w = 5;
     if (threads == 512 && w > 6) w = 6;
     uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
+    // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
+    // resident workgroup (random-spheres: 49.6 KB scene copy, 3 workgroups of 512 lanes per CU without it, 2 with it:
+    // measured 7 % slower than register slots); otherwise the slots are registers
+    const uint32_t slots = ra_all.leaf_slots < 1u ? 1u : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
+    const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
+    const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
+    bool lds_stack = ra_all.lds_leaf_stack != 0u;
+    if (lds_stack && ra_all.lds_leaf_stack != 2u) {
+        const uint32_t fit_plain = scene_bytes ? (uint32_t)(160u * 1024u / scene_bytes) : wg_per_cu;
+        const uint32_t fit_stack = (uint32_t)(160u * 1024u / with_stack);
+        lds_stack = (fit_stack < wg_per_cu ? fit_stack : wg_per_cu) >= (fit_plain < wg_per_cu ? fit_plain : wg_per_cu);
+    }
+    const size_t lds_bytes = lds_stack ? with_stack : scene_bytes;
     if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
     const uint32_t resident = (uint32_t)cus * wg_per_cu;
     const uint32_t waves_per_wg = (uint32_t)threads / 64u;
     bool first = true;
     for (uint32_t s0 = ra_all.sample_begin; s0 < ra_all.sample_end; s0 += chunk) {
         RenderArgs ra = ra_all;
+        ra.lds_leaf_stack = lds_stack ? 1u : 0u;
+        if (lds_stack) ra.leaf_slots = slots;
         ra.sample_begin = s0;
         ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;
         uint32_t batch_spp = kBatchSpp;
