@@ -177,10 +177,10 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const size_t scene_bytes = scene_lds_bytes(sc.L);
     const int mode = scene_mode(sc.L);
-    // waves per SIMD / lanes per workgroup as in kernels.hip: 7 waves for small LDS copies, 512-lane workgroups sharing a
-    // big LDS copy between 8 waves, no cap for scenes read from global memory
+    // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies, 512-lane workgroups sharing a big
+    // LDS copy between 8 waves, 5 waves per SIMD for scenes read from global memory
     const int threads = (mode == MODE_LDS && sc.L.hot_bytes > 20u * 1024u) ? 512 : 256;
-    int w = mode == MODE_LDS ? (threads == 512 ? 6 : 7) : 5;
+    int w = mode == MODE_LDS ? 6 : 5;            // 6 waves per SIMD (80 VGPRs, 21 spilled) beat 7 (72 VGPRs, 38 spilled) by 3 % and 5 (no spills) by 2 % on Cornell
     if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
     if (w < 5) w = 5;
     if (threads == 512 && w > 6) w = 6;
