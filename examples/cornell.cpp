@@ -2,7 +2,7 @@
 // same camera, same Renderer::new(300, 8, 20, true, Some(0.001)) arguments, on an MI355X.
 //
 //   g++ -std=c++17 -Iinclude examples/cornell.cpp -Ltiny-raytracer_amd -ltinyrt -Wl,-rpath,$PWD/tiny-raytracer_amd -o build/cornell
-//   ./build/cornell [width height spp] -> output.ppm
+//   ./build/cornell [width height spp] -> output.png
 #include <cstdio>
 #include <cstdlib>
 
@@ -40,8 +40,8 @@ int main(int argc, char** argv) {
         Renderer instance(spp, 8, 20, true, Vec3::new_diagonal(0.001f));
         trt_stats st{};
         Image image = instance.render(camera, world, &st);
-        image.save("output.ppm");
-        std::printf("%ux%u, %u spp: %llu rays in %.2f ms (%.1f Mray/s) -> output.ppm\n", w, h, spp, (unsigned long long)st.rays,
+        image.save("output.png");                                      // src/main.rs:20
+        std::printf("%ux%u, %u spp: %llu rays in %.2f ms (%.1f Mray/s) -> output.png\n", w, h, spp, (unsigned long long)st.rays,
                     st.kernel_ms, st.rays / st.kernel_ms / 1e3);
     } catch (const Error& e) {
         std::fprintf(stderr, "%s\n", e.what());

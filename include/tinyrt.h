@@ -169,6 +169,11 @@ int trt_sample_batch(trt_scene *s, const trt_sample_point *in, uint32_t n, trt_s
  * clamp to [0, 0.999], *255, truncate; NaN -> 0.  HOST buffers, npixels*3 each. */
 int trt_tonemap_u8(const float *accum, uint32_t npixels, float gamma, uint8_t *rgb);
 
+/* The same on buffers resident in HBM (device pointers), asynchronous on `stream` (a hipStream_t, NULL = default): the
+ * frame never has to leave the GPU as f32.  c^(1/gamma) is evaluated in f64 on the device; against the host form
+ * (libm powf) a channel may differ by one least-significant bit where powf is not correctly rounded. */
+int trt_tonemap_u8_device(const float *d_accum, uint32_t npixels, float gamma, uint8_t *d_rgb, void *stream);
+
 /* Samples per pixel the streamed backend traces per kernel launch for an image of this size (it splits longer sample
  * ranges into such chunks; one chunk = one `trt::stream_sample_kernel` launch + one fold launch). */
 uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows);

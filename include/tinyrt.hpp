@@ -110,6 +110,58 @@ public:
     trt_camera pod;
 };
 
+// Minimal PNG writer (8-bit RGB, zlib "stored" blocks: valid for every decoder, no compression) so that
+// Image::save("x.png") yields what the reference's `image` crate call yields: a PNG of the quantised frame.
+namespace detail {
+inline uint32_t crc32(const uint8_t* p, size_t n, uint32_t crc) {
+    crc = ~crc;
+    for (size_t i = 0; i < n; i++) {
+        crc ^= p[i];
+        for (int k = 0; k < 8; k++) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+    }
+    return ~crc;
+}
+inline void put_be32(std::vector<uint8_t>& v, uint32_t x) {
+    v.push_back((uint8_t)(x >> 24)); v.push_back((uint8_t)(x >> 16)); v.push_back((uint8_t)(x >> 8)); v.push_back((uint8_t)x);
+}
+inline void png_chunk(std::vector<uint8_t>& out, const char* type, const std::vector<uint8_t>& data) {
+    put_be32(out, (uint32_t)data.size());
+    const size_t at = out.size();
+    out.insert(out.end(), type, type + 4);
+    out.insert(out.end(), data.begin(), data.end());
+    put_be32(out, crc32(out.data() + at, out.size() - at, 0u));
+}
+inline std::vector<uint8_t> encode_png_rgb8(const uint8_t* rgb, uint32_t w, uint32_t h) {
+    std::vector<uint8_t> out = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    std::vector<uint8_t> ihdr;
+    put_be32(ihdr, w); put_be32(ihdr, h);
+    ihdr.insert(ihdr.end(), {8, 2, 0, 0, 0});                       // 8 bits, colour type 2 (RGB), deflate, no filter, no interlace
+    png_chunk(out, "IHDR", ihdr);
+    std::vector<uint8_t> raw;                                        // scanlines, each with filter byte 0
+    raw.reserve((size_t)h * ((size_t)w * 3 + 1));
+    for (uint32_t y = 0; y < h; y++) {
+        raw.push_back(0);
+        raw.insert(raw.end(), rgb + (size_t)y * w * 3, rgb + (size_t)(y + 1) * w * 3);
+    }
+    std::vector<uint8_t> z = {0x78, 0x01};                           // zlib header, then stored deflate blocks of <= 65535 bytes
+    uint32_t a = 1, b = 0;                                           // Adler-32 of the raw data
+    for (uint8_t c : raw) { a = (a + c) % 65521u; b = (b + a) % 65521u; }
+    size_t pos = 0;
+    do {
+        const size_t n = raw.size() - pos < 65535 ? raw.size() - pos : 65535;
+        z.push_back(pos + n == raw.size() ? 1 : 0);
+        z.push_back((uint8_t)(n & 0xFF)); z.push_back((uint8_t)(n >> 8));
+        z.push_back((uint8_t)(~n & 0xFF)); z.push_back((uint8_t)((~n >> 8) & 0xFF));
+        z.insert(z.end(), raw.begin() + (long)pos, raw.begin() + (long)(pos + n));
+        pos += n;
+    } while (pos < raw.size());
+    put_be32(z, b << 16 | a);
+    png_chunk(out, "IDAT", z);
+    png_chunk(out, "IEND", {});
+    return out;
+}
+}  // namespace detail
+
 // utils/image.rs: Image with gamma 2.2 as the Imager builds it (imager.rs:37-41); holds the linear sums
 class Image {
 public:
@@ -123,13 +175,19 @@ public:
         check(trt_tonemap_u8(data_.data(), width_ * height_, gamma_, rgb.data()));
         return rgb;
     }
-    // Image::save writes a PNG through the `image` crate (image.rs:66-69); this mirror writes binary PPM
+    // Image::save (image.rs:66-69; the reference writes PNG through the `image` crate): PNG for "*.png", binary PPM otherwise
     void save(const std::string& filename) const {
         auto rgb = to_rgb8();
         FILE* f = std::fopen(filename.c_str(), "wb");
         if (!f) throw Error(TRT_ERR_INVALID_ARG, "cannot open " + filename);
-        std::fprintf(f, "P6\n%u %u\n255\n", width_, height_);
-        std::fwrite(rgb.data(), 1, rgb.size(), f);
+        const bool png = filename.size() >= 4 && filename.compare(filename.size() - 4, 4, ".png") == 0;
+        if (png) {
+            auto bytes = detail::encode_png_rgb8(rgb.data(), width_, height_);
+            std::fwrite(bytes.data(), 1, bytes.size(), f);
+        } else {
+            std::fprintf(f, "P6\n%u %u\n255\n", width_, height_);
+            std::fwrite(rgb.data(), 1, rgb.size(), f);
+        }
         std::fclose(f);
     }
 

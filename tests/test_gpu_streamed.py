@@ -169,3 +169,32 @@ def test_leaf_slots_are_scheduling_only(trt, monkeypatch, scene):
     plain = r.render(pcam, pw)                                                      # production (non-counting) kernel, defaults
     assert np.array_equal(plain.data.view(np.uint32), ref_img.view(np.uint32))
     assert r.last_stats["rays"] == ref_stats["rays"]
+
+
+def test_device_tonemap_matches_host_form(trt):
+    """SURVEY 8 f1 on the device: the frame is rendered, gamma-corrected and quantised without leaving HBM; against the
+    host form (libm powf, = the oracle's) a channel may differ by one LSB where powf is not correctly rounded."""
+    import torch
+    dev = torch.device("cuda:0")
+    desc = trt.scenes.cornell(301, 203)                                    # odd sizes: the 4-channel vector path has a tail
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(16, 1, 12, False, desc["background"], seed=3)
+    acc = torch.zeros((203, 301, 3), device=dev)
+    stream = torch.cuda.current_stream()
+    r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream)
+    rgb = torch.zeros((203, 301, 3), dtype=torch.uint8, device=dev)
+    trt.tonemap_u8_device(acc.data_ptr(), 203 * 301, rgb.data_ptr(), 2.2, stream.cuda_stream)
+    torch.cuda.synchronize()
+    host = trt.Image(acc.cpu().numpy()).to_u8()
+    d = np.abs(rgb.cpu().numpy().astype(np.int16) - host.astype(np.int16))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-3
+    # special values, unaligned buffers (scalar path): NaN -> 0, negative -> 0, >= 1 -> 254, inf -> 254
+    special = torch.tensor([float("nan"), -1.0, 0.0, 1e-9, 0.5, 0.999, 1.0, 7.0, float("inf"), 0.25, 0.125, 0.73], device=dev)
+    buf = torch.zeros(16, device=dev)
+    buf[1:13] = special
+    out = torch.zeros(16, dtype=torch.uint8, device=dev)
+    trt.tonemap_u8_device(buf.data_ptr() + 4, 4, out.data_ptr() + 1, 2.2, stream.cuda_stream)
+    torch.cuda.synchronize()
+    ref = trt.Image(special.cpu().numpy().reshape(1, 4, 3)).to_u8().ravel()
+    assert np.abs(out.cpu().numpy()[1:13].astype(np.int16) - ref.astype(np.int16)).max() <= 1
+    assert list(out.cpu().numpy()[[1, 2, 3, 7, 8, 9]]) == [0, 0, 0, 254, 254, 254]

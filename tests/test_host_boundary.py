@@ -191,3 +191,28 @@ def test_culling_tree_is_a_hierarchy_over_the_reference_leaf_sequence(trt, scene
         # children are complete subtrees: every node strictly inside (i, skip[i]) ends inside
         assert (cs[i + 1:cs[i]] <= cs[i]).all()
     assert leaf_rank[-1] + (cp[-1] >= 0) == len(ref_leaves)
+
+
+@pytest.mark.parametrize("size", [(37, 23), (300, 260)])              # the second one needs more than one 65535-byte stored block
+def test_cpp_image_save_writes_a_valid_png(trt, tmp_path, size):
+    """tinyrt::Image::save (utils/image.rs:66-69 writes PNG): the header-only PNG writer decodes (PIL) to exactly the
+    library's quantised frame, and the PPM form carries the same bytes."""
+    import subprocess
+    from PIL import Image as PILImage
+    w, h = size
+    exe = str(tmp_path / "image_save_check")
+    libdir = os.path.join(ROOT, "tiny-raytracer_amd")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "native", "image_save_check.cpp"), "-L" + libdir, "-ltinyrt", "-Wl,-rpath," + libdir,
+                    "-o", exe], check=True)
+    png, ppm = str(tmp_path / "o.png"), str(tmp_path / "o.ppm")
+    subprocess.run([exe, str(w), str(h), png, ppm], check=True)
+    x, y = np.meshgrid(np.arange(w, dtype=np.float32), np.arange(h, dtype=np.float32))
+    lin = np.stack([x / np.float32(w), y / np.float32(h) * np.float32(1.5),
+                    np.where((x + y) % 7 == 0, np.float32(-0.25), np.float32(0.18))], axis=-1).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+        want = trt.Image(lin).to_u8()
+    got = np.asarray(PILImage.open(png).convert("RGB"))
+    assert got.shape == (h, w, 3) and np.array_equal(got, want)
+    assert np.array_equal(np.asarray(PILImage.open(ppm).convert("RGB")), want)
+    assert want[..., 1].max() == 254 and want[0, 0, 2] == 0

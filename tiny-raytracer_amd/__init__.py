@@ -7,7 +7,7 @@ from . import scenes  # noqa: F401
 from ._lib import (BACKEND_AUTO, BACKEND_MEGAKERNEL, BACKEND_STREAMED, BACKEND_WAVEFRONT, DIELECTRIC, LAMBERTIAN, LIGHT, METAL, CameraPOD,  # noqa: F401
                    Material, Ray, RenderParams, SampledColor, SamplePoint, Stats, TinyRTError, Vec3, lib)
 from .api import (Camera, Dielectric, Image, Lambertian, Light, Metal, Quad, Renderer, Scene, Sphere, World,  # noqa: F401
-                  sample_batch)
+                  sample_batch, tonemap_u8_device)
 
 _MATERIAL_CTORS = {LAMBERTIAN: lambda a, p: Lambertian(a), METAL: Metal, DIELECTRIC: Dielectric,
                    LIGHT: lambda a, p: Light(a)}

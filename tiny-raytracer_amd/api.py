@@ -212,6 +212,12 @@ class Renderer:
                                     C.c_void_p(d_counters_ptr), C.c_void_p(stream_ptr)))
 
 
+def tonemap_u8_device(d_accum_ptr, npixels, d_rgb_ptr, gamma=2.2, stream_ptr=0):
+    """Imager finalisation on buffers in HBM (device pointers as integers): linear f32 sums -> gamma-corrected RGB8."""
+    check(lib.trt_tonemap_u8_device(C.c_void_p(d_accum_ptr), int(npixels), float(gamma), C.c_void_p(d_rgb_ptr),
+                                    C.c_void_p(stream_ptr)))
+
+
 def sample_batch(scene, points, max_bounces, background, seed=1):
     """trait Sampler in batch form: numpy structured array of SamplePoint -> SampledColor."""
     n = len(points)

@@ -437,4 +437,14 @@ int trt_tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* r
     return TRT_OK;
 }
 
+// The same on buffers resident in HBM; asynchronous on `stream`.
+int trt_tonemap_u8_device(const float* d_accum, uint32_t npixels, float gamma, uint8_t* d_rgb, void* stream) {
+    if (npixels && (!d_accum || !d_rgb)) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    if (!(gamma > 0.0f)) return fail(TRT_ERR_INVALID_ARG, "gamma must be positive");
+    int rc = require_device();
+    if (rc != TRT_OK) return rc;
+    TRT_HIP(launch_tonemap_u8(d_accum, npixels, gamma, d_rgb, reinterpret_cast<hipStream_t>(stream)));
+    return TRT_OK;
+}
+
 }  // extern "C"

@@ -74,6 +74,9 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                            unsigned long long* d_counters, bool stats, hipStream_t stream);
 
 // Sampler plug-in form: n caller-supplied rays.
+// Imager finalisation on buffers in HBM (kernels.hip).
+hipError_t launch_tonemap_u8(const float* d_accum, unsigned long long npixels, float gamma, uint8_t* d_rgb, hipStream_t stream);
+
 hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out,
                                const RenderArgs& ra, unsigned long long* d_counters, bool stats, hipStream_t stream);
 

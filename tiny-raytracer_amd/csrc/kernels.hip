@@ -197,4 +197,46 @@ hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Imager finalisation on the device: Color::gamma_correction + From<Color> for Rgb<u8>
+// (utils/image.rs:92-111): c^(1/gamma), clamp to [0, 0.999], * 255, truncate; NaN -> 0.  Elementwise and HBM-bound:
+// 12 bytes read + 3 written per pixel, four channels per lane (one 16-byte load, one 4-byte store).
+// c^(1/gamma) is evaluated in f64 and rounded to f32, which agrees with a correctly rounded powf (the host's and the
+// oracle's libm) except where powf itself is off by an ulp; frames are compared with a +-1 LSB allowance - this step
+// is outside the path's parity target, the linear sums are the product.
+// ------------------------------------------------------------------------------------------------
+TRT_DEV uint32_t quantise_channel(float c, double inv_gamma) {
+    float g = (float)pow((double)c, inv_gamma);
+    if (g < 0.000f) g = 0.000f;
+    if (g > 0.999f) g = 0.999f;
+    const float s = g * 255.0f;
+    if (!(s == s) || s <= 0.0f) return 0u;
+    return s >= 255.0f ? 255u : (uint32_t)s;
+}
+
+__global__ __launch_bounds__(256) void tonemap_u8_kernel(const float* __restrict__ accum, unsigned long long n_channels,
+                                                         float inv_gamma, uint8_t* __restrict__ rgb, uint32_t vectorised) {
+    const double ig = (double)inv_gamma;
+    const unsigned long long i4 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
+    if (i4 >= n_channels) return;
+    if (vectorised && i4 + 4ull <= n_channels) {
+        const float4 v = *reinterpret_cast<const float4*>(accum + i4);
+        const uint32_t q = quantise_channel(v.x, ig) | quantise_channel(v.y, ig) << 8 | quantise_channel(v.z, ig) << 16 |
+                           quantise_channel(v.w, ig) << 24;
+        *reinterpret_cast<uint32_t*>(rgb + i4) = q;
+    } else {
+        for (unsigned long long i = i4; i < i4 + 4ull && i < n_channels; i++) rgb[i] = (uint8_t)quantise_channel(accum[i], ig);
+    }
+}
+
+hipError_t launch_tonemap_u8(const float* d_accum, unsigned long long npixels, float gamma, uint8_t* d_rgb, hipStream_t stream) {
+    const unsigned long long n_channels = npixels * 3ull;
+    if (n_channels == 0ull) return hipSuccess;
+    const uint32_t vectorised = (reinterpret_cast<uintptr_t>(d_accum) % 16u == 0u && reinterpret_cast<uintptr_t>(d_rgb) % 4u == 0u) ? 1u : 0u;
+    const unsigned long long lanes = (n_channels + 3ull) / 4ull;
+    const dim3 grid((uint32_t)((lanes + 255ull) / 256ull)), block(256);
+    hipLaunchKernelGGL(tonemap_u8_kernel, grid, block, 0, stream, d_accum, n_channels, 1.0f / gamma, d_rgb, vectorised);
+    return hipGetLastError();
+}
+
 }  // namespace trt
