@@ -77,3 +77,26 @@ def test_large_random_scene_from_global_memory(trt, orc):
     pw, _ = trt.world_from_description(desc)
     assert pw.get_bvh().info()["lds_bytes"] == 0
     check(trt, orc, desc, spp=2, depth=8)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_walk_schedules_agree_on_many_rays(trt, monkeypatch, seed):
+    """GPU against GPU, ~10^8 rays per scene (the oracle checks above see ~10^5): the postponed-leaf walk with its slots
+    in LDS or in registers, the plain one-slot walk and the megakernel run the same primitive tests and give the same
+    frame on mixed random scenes (overlapping spheres and quads, all materials): rounding-level hazards of the
+    speculative walk would show here as a differing ray count."""
+    desc = random_scene(300 + seed, n_prims=int(20 + 60 * seed), width=1280, height=800)
+    pw, pcam = trt.world_from_description(desc)
+    ref_img = ref_stats = None
+    for backend, slots, lds in ((3, "1", "0"), (3, "4", "2"), (3, "4", "0"), (3, "2", "0"), (0, "4", "0"), (3, "8", "2")):
+        monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
+        monkeypatch.setenv("TRT_LDS_LEAF_STACK", lds)
+        r = trt.Renderer(16, 1, 16, False, desc["background"], seed=11, backend=backend)
+        img = r.render(pcam, pw, collect_stats=2)
+        st = dict(r.last_stats)
+        if ref_img is None:
+            ref_img, ref_stats = img.data.copy(), st
+            continue
+        assert_bit_equal(img.data, ref_img, f"{desc['name']} backend {backend} slots {slots} lds {lds}")
+        for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
+            assert st[k] == ref_stats[k], (backend, slots, lds, k)
