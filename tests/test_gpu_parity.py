@@ -305,13 +305,12 @@ def test_cpp_mirror_renders_the_same_frame(trt, tmp_path):
     exe = _build_cpp_example(tmp_path)
     r = subprocess.run([exe, "72", "56", "5"], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr
-    ppm = open(tmp_path / "output.ppm", "rb").read()
-    header = b"P6\n72 56\n255\n"
-    assert ppm.startswith(header)
+    from PIL import Image as PILImage
+    got = np.asarray(PILImage.open(tmp_path / "output.png").convert("RGB"))          # src/main.rs:20 saves a PNG
     desc = trt.scenes.cornell(72, 56)
     pw, pcam = trt.world_from_description(desc)
     img = trt.Renderer(5, 8, 20, True, (0.001, 0.001, 0.001)).render(pcam, pw)
-    assert ppm[len(header):] == img.to_u8().tobytes()
+    assert got.shape == (56, 72, 3) and np.array_equal(got, img.to_u8())
 
 
 def test_default_backend_is_auto_and_matches_the_oracle(trt, orc):

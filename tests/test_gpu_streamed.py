@@ -198,3 +198,33 @@ def test_device_tonemap_matches_host_form(trt):
     ref = trt.Image(special.cpu().numpy().reshape(1, 4, 3)).to_u8().ravel()
     assert np.abs(out.cpu().numpy()[1:13].astype(np.int16) - ref.astype(np.int16)).max() <= 1
     assert list(out.cpu().numpy()[[1, 2, 3, 7, 8, 9]]) == [0, 0, 0, 254, 254, 254]
+
+
+def test_lockstep_leaf_list_is_scheduling_only(trt, orc, monkeypatch):
+    """Scenes with at most 32 primitives are walked as a lock-step leaf list (rt_path.h walk_flat, wave-uniform nodes
+    from the scalar cache) instead of through the culling tree: same frame, same primitive tests, as the tree walk,
+    the plain one-slot walk and the oracle."""
+    desc = trt.scenes.cornell(320, 320)
+    ow, ocam = orc.world_from_description(desc)
+    cpu, cst = orc.render(ow, ocam, 8, 50, desc["background"], seed=9, nthreads=8)
+    results = []
+    for flat, slots in (("0", "1"), ("1", "0"), ("1", "2"), ("1", "12"), ("0", "0")):
+        monkeypatch.setenv("TRT_FLAT_WALK", flat)                                   # read when the scene is compiled
+        if slots == "0":
+            monkeypatch.delenv("TRT_LEAF_SLOTS", raising=False)
+        else:
+            monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
+        pw, pcam = trt.world_from_description(desc)
+        r = trt.Renderer(8, 1, 50, False, desc["background"], seed=9, backend=STREAMED)
+        img = r.render(pcam, pw, collect_stats=2)
+        results.append((flat, slots, img.data.copy(), dict(r.last_stats)))
+        plain = r.render(pcam, pw)                                                  # production kernel
+        assert_bit_equal(plain.data, cpu, f"flat {flat} slots {slots} vs oracle")
+    for flat, slots, data, st in results:
+        assert_bit_equal(data, cpu, f"counting kernel, flat {flat} slots {slots}")
+        for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
+            assert st[k] == cst[k], (flat, slots, k)
+    tree, flat_default = results[4][3], results[1][3]
+    # every ray steps every leaf box (but for the handful of NaN-prone rays that take the reference tree)
+    assert abs(flat_default["node_tests"] - 18 * flat_default["rays"]) < 1e-4 * flat_default["node_tests"]
+    assert tree["node_tests"] < flat_default["node_tests"]

@@ -115,8 +115,8 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
         ra.band_rows = p->band_rows; ra.band_stride = p->band_stride; ra.band_offset = p->band_offset;
     }
     ra.rows_local = rows;
-    ra.leaf_slots = 4u;                                    // rt_path.h walk_fast; scheduling only, any value renders the same frame
-    if (const char* e = getenv("TRT_LEAF_SLOTS")) ra.leaf_slots = (uint32_t)atoi(e) ? (uint32_t)atoi(e) : 4u;
+    ra.leaf_slots = 0u;                                    // rt_path.h walk_fast; 0 = the backend's default; scheduling only, any value renders the same frame
+    if (const char* e = getenv("TRT_LEAF_SLOTS")) ra.leaf_slots = (uint32_t)atoi(e);
     ra.lds_leaf_stack = 1u;
     if (const char* e = getenv("TRT_LDS_LEAF_STACK")) ra.lds_leaf_stack = (uint32_t)atoi(e);   // 0 off, 1 where it costs no occupancy, 2 always
     ra.xcd_aware = getenv("TRT_XCD_REMAP") ? 1u : 0u;   // off: contiguous image regions per XCD measured 2x slower (load imbalance)

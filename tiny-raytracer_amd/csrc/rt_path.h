@@ -270,18 +270,55 @@ TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
     }
 }
 
-constexpr uint32_t kLdsLeafSlotsMax = 8;  // most slots per lane of the LDS leaf stack (8 bytes each)
+// Scenes with a handful of primitives (SceneLayout::flat_walk): no tree at all.  Every lane of the wave steps the SAME
+// leaf box in the same trip - the list of leaves in walk order - so the node is wave-uniform: it comes through the
+// scalar cache into SGPRs (`leaf_list` must be a __restrict__ kernel argument for that), there is no per-lane address,
+// no LDS read and no cursor, and all lanes are busy in every box step: 18 trips of ~28 VALU instructions for
+// Cornell's 18 quads against ~20 trips of ~35 at 53 % occupancy through the culling tree.  It is the culling tree
+// with every inner node pruned, so the argument of walk_fast applies unchanged: leaves whose box passes are put
+// aside with their `start` and tested in walk order, each only if its box still passes with the current t_best.
+// All lanes that call this must enter together (they do: a wave's lanes start their walks in the same trip).
+template <int MODE, bool STATS>
+TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf_list, const Ray& ray, Trav& tr, Counters<STATS>& ctr,
+                       float2* stk, uint32_t slots) {
+    const uint32_t n = sc.L.n_leaves;
+    uint32_t i = 0;                                      // wave-uniform
+    do {
+        uint32_t cnt = 0;
+        for (; i < n;) {
+            const float4 na = leaf_list[2u * i], nb = leaf_list[2u * i + 1u];
+            i++;
+            if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+            float start;
+            if (slab_fast_entry(na, nb, ray.o, tr.inv, kTMin, tr.t_best, start)) {
+                stk[64u * cnt] = make_float2(nb.w, start);
+                cnt++;
+            }
+            if (__builtin_amdgcn_ballot_w64(cnt >= slots) != 0ull) break;        // some lane's slots are full: test what is pending
+        }
+        for (uint32_t k = 0; k < cnt; k++) {
+            const float2 e = stk[64u * k];
+            if (tr.t_best > e.y) {                                                  // the leaf's box test with the current t_best
+                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+                trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(e.x), ctr);
+            }
+        }
+    } while (i < n);
+}
+
+constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)
 
 // Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  Postponed leaves go to
 // `lds_stack` (this lane's slot 0 of a `leaf_slots`-deep LDS stack) if the kernel has one, else into registers:
-// `leaf_slots` = 4 (default), 2 or 1 (tuning and tests; wave-uniform).
+// `leaf_slots` = 4 (also for 0 = default), 2 or 1 (tuning and tests; wave-uniform).
 template <int MODE, bool STATS>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
-                             uint32_t leaf_slots = 4u, float2* lds_stack = nullptr) {
+                             uint32_t leaf_slots = 4u, float2* lds_stack = nullptr, const float4* __restrict__ leaf_list = nullptr) {
     Trav tr = trav_begin(sc, ray, ref_tree);
     if (__builtin_expect(!tr.ref, 1)) {
-        if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
-        else if (leaf_slots >= 4u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
+        if (lds_stack != nullptr && leaf_list != nullptr) walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+        else if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
+        else if (leaf_slots >= 4u || leaf_slots == 0u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
         else if (leaf_slots >= 2u) walk_fast<MODE, STATS, 2>(sc, ray, tr, ctr);
         else walk_fast<MODE, STATS, 1>(sc, ray, tr, ctr);
     } else {

@@ -65,6 +65,7 @@ struct World {
 //   [material: nm] (albedo.rgb, param)
 //   [sphere_material: ns] u32   [material_kind: nm] u32          (padded to 16 bytes)   <- hot_bytes end here
 //   [reference nodes: 2n] same node format
+//   [leaf list: 2 per leaf] the leaves of the trees in walk order, same node format (skip = successor)
 struct SceneLayout {
     uint32_t n_nodes;           // reference tree (2N-1)
     uint32_t n_cull_nodes;      // culling tree
@@ -75,7 +76,11 @@ struct SceneLayout {
     uint32_t off_ref_nodes;                                       // in 16-byte elements
     uint32_t hot_bytes, blob_bytes;
     uint32_t all_finite;        // 1: every coordinate is finite and small enough for the fast slab test
+    uint32_t n_leaves;          // leaves of either tree (= primitives), in walk order
+    uint32_t off_leaf_list;     // in 16-byte elements: the leaves alone, node format, skip = successor (cold part of the blob)
+    uint32_t flat_walk;         // 1: few enough leaves that the streamed kernel steps the leaf list in lock-step (rt_path.h walk_flat)
 };
+constexpr uint32_t kFlatWalkMaxLeaves = 32;   // at most this many primitives: lock-step leaf list instead of the culling tree
 
 struct NodeDump {                            // pre-order inspection copy of one tree
     std::vector<float> bbox6;

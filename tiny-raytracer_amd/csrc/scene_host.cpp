@@ -255,8 +255,12 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     uint32_t n_u32 = L.off_material_kind + nm;
     L.hot_bytes = ((n_u32 * 4u) + 15u) & ~15u;
     L.off_ref_nodes = L.hot_bytes / 16u;
-    L.blob_bytes = L.hot_bytes + 32u * nn;
+    L.n_leaves = (uint32_t)leaf_box.size();
+    L.off_leaf_list = L.off_ref_nodes + 2u * nn;
+    L.blob_bytes = L.hot_bytes + 32u * nn + 32u * L.n_leaves;
     L.all_finite = all_finite ? 1u : 0u;
+    L.flat_walk = L.n_leaves <= kFlatWalkMaxLeaves ? 1u : 0u;
+    if (const char* e = getenv("TRT_FLAT_WALK")) L.flat_walk = atoi(e) ? 1u : 0u;            // tuning / tests; same frames either way
 
     out.blob.assign(L.blob_bytes, 0);
     F4* f4 = reinterpret_cast<F4*>(out.blob.data());
@@ -311,6 +315,13 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     L.n_top_nodes = n_top;
     pack_nodes(f4, cb.node_box, cull_prim_geo, cb.node_skip, cull_place);
     pack_nodes(f4 + L.off_ref_nodes, b.node_box, b.node_prim, b.node_skip, ref_place);
+    {   // leaf list: the leaves alone, in walk order
+        const uint32_t nl = L.n_leaves;
+        std::vector<int32_t> lprim(leaf_geo.begin(), leaf_geo.end()), lskip(nl);
+        std::vector<uint32_t> lplace(nl);
+        for (uint32_t k = 0; k < nl; k++) { lskip[k] = (int32_t)k + 1; lplace[k] = k; }
+        pack_nodes(f4 + L.off_leaf_list, leaf_box, lprim, lskip, lplace);
+    }
     dump_tree(out.reference, b.node_box, b.node_prim, b.node_skip);
     dump_tree(out.culling, cb.node_box, cull_prim_geo, cb.node_skip);
     for (uint32_t i = 0; i < ns; i++) { f4[L.off_sphere + i] = spheres[i]; u32[L.off_sphere_mat + i] = sphere_mat[i]; }

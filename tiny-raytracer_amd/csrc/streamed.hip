@@ -36,7 +36,8 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                                                                              float* __restrict__ colors,
                                                                              uint32_t* __restrict__ batch_counter,
                                                                              unsigned long long* __restrict__ counters,
-                                                                             uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp) {
+                                                                             uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp,
+                                                                             const float4* __restrict__ leaf_list) {
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
     const uint32_t lane = threadIdx.x & 63u;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack);
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -188,7 +189,10 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
     // resident workgroup (random-spheres: 49.6 KB scene copy, 3 workgroups of 512 lanes per CU without it, 2 with it:
     // measured 7 % slower than register slots); otherwise the slots are registers
-    const uint32_t slots = ra_all.leaf_slots < 1u ? 1u : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
+    // slots of the LDS stack: 4 for tree walks; 6 for the lock-step leaf list, whose t_best stays stale for a whole walk
+    // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12)
+    const bool flat = sc.L.flat_walk && !ra_all.ref_tree;
+    const uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 6u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
     const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
     const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
     bool lds_stack = ra_all.lds_leaf_stack != 0u;
@@ -198,6 +202,8 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         lds_stack = (fit_stack < wg_per_cu ? fit_stack : wg_per_cu) >= (fit_plain < wg_per_cu ? fit_plain : wg_per_cu);
     }
     const size_t lds_bytes = lds_stack ? with_stack : scene_bytes;
+    // few primitives: lock-step leaf list (rt_path.h walk_flat); needs the LDS stack for its postponed leaves
+    const float4* leaf_list = (lds_stack && flat) ? sc.blob + sc.L.off_leaf_list : nullptr;
     if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
     const uint32_t resident = (uint32_t)cus * wg_per_cu;
     const uint32_t waves_per_wg = (uint32_t)threads / 64u;
@@ -222,7 +228,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                 if (e2 != hipSuccess) return e2;
             }
-            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches, batch_spp);
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches, batch_spp, leaf_list);
             return hipGetLastError();
         };
         switch (mode) {
