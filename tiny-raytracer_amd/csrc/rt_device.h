@@ -86,23 +86,19 @@ TRT_DEV float dm_asin_poly(float z) {
            + 1.6666752422e-1f;
 }
 
+// Branch-free form of the three-range evaluation (|x| <= 0.5: pi/2 - asin(x); x > 0.5: 2 asin(sqrt((1-x)/2));
+// x < -0.5: pi - 2 asin(sqrt((1+x)/2))): every lane performs exactly the operations of its own range (1 + x for a
+// negative x IS 1 - |x|), selected instead of branched to - the lanes of a wave fall into all three ranges
+// (x = 1 - 2u), so branches made the wave issue all three bodies.
 TRT_DEV float dm_acos(float x) {
     const float PI_F = 3.14159265358979323846f, PIO2_F = 1.57079632679489661923f;
-    if (x > 0.5f) {
-        float z = 0.5f * (1.0f - x);
-        float s = __builtin_sqrtf(z);
-        float r = dm_asin_poly(z) * z * s + s;
-        return r + r;
-    }
-    if (x < -0.5f) {
-        float z = 0.5f * (1.0f + x);
-        float s = __builtin_sqrtf(z);
-        float r = dm_asin_poly(z) * z * s + s;
-        return PI_F - (r + r);
-    }
-    float z = x * x;
-    float r = dm_asin_poly(z) * z * x + x;
-    return PIO2_F - r;
+    const float ax = __builtin_fabsf(x);
+    const bool big = ax > 0.5f;
+    const float z = big ? 0.5f * (1.0f - ax) : x * x;
+    const float w = big ? __builtin_sqrtf(z) : x;
+    const float r = dm_asin_poly(z) * z * w + w;
+    const float two_r = r + r;
+    return big ? (x > 0.0f ? two_r : PI_F - two_r) : PIO2_F - r;
 }
 
 // cube root: exponent/3 bit guess, two Halley steps; the second in residual form (< 1 ulp).
