@@ -81,7 +81,7 @@ def cpu_baseline(trt, desc, depth, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--spp-per-step", type=int, default=256)
     ap.add_argument("--backend", default="auto", choices=["auto", "megakernel", "wavefront", "streamed"],
