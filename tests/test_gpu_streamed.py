@@ -228,3 +228,34 @@ def test_lockstep_leaf_list_is_scheduling_only(trt, orc, monkeypatch):
     # every ray steps every leaf box (but for the handful of NaN-prone rays that take the reference tree)
     assert abs(flat_default["node_tests"] - 18 * flat_default["rays"]) < 1e-4 * flat_default["node_tests"]
     assert tree["node_tests"] < flat_default["node_tests"]
+
+
+def test_full_size_schedules_agree_cornell_2048(trt, monkeypatch):
+    """BASELINE's full frame size, 64 spp (1.9e9 rays per render): the shipped schedule (lock-step leaf list, 6 LDS
+    slots), the culling-tree walk with LDS slots, the plain one-slot tree walk and the megakernel give the same frame
+    and the same ray count - every scheduling layer added on top of the reference's walk is checked at full size."""
+    import torch
+    dev = torch.device("cuda:0")
+    desc = trt.scenes.cornell(2048, 2048)
+    stream = torch.cuda.current_stream()
+    ref = ref_rays = None
+    for backend, flat, slots, lds in ((STREAMED, "1", None, None), (STREAMED, "0", None, None), (STREAMED, "0", "1", "0"), (0, "0", "1", "0")):
+        monkeypatch.setenv("TRT_FLAT_WALK", flat)
+        for k, v in (("TRT_LEAF_SLOTS", slots), ("TRT_LDS_LEAF_STACK", lds)):
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        pw, pcam = trt.world_from_description(desc)
+        r = trt.Renderer(64, 1, 50, False, desc["background"], seed=1, backend=backend)
+        acc = torch.zeros((2048, 2048, 3), device=dev)
+        ctr = torch.zeros(16, dtype=torch.int64, device=dev)
+        r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream, ctr.data_ptr())
+        torch.cuda.synchronize()
+        rays = int(ctr[1].item())
+        if ref is None:
+            ref, ref_rays = acc, rays
+            assert rays > 1.8e9
+            continue
+        assert rays == ref_rays, (backend, flat, slots, lds)
+        assert torch.equal(acc.view(torch.int32), ref.view(torch.int32)), (backend, flat, slots, lds)
