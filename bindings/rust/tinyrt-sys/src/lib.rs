@@ -151,6 +151,7 @@ extern "C" {
     pub fn trt_scene_get_info(s: *const trt_scene, out: *mut trt_scene_info) -> c_int;
     pub fn trt_scene_get_nodes(s: *const trt_scene, bbox6: *mut f32, prim: *mut i32, skip: *mut i32, cap: u32) -> c_int;
     pub fn trt_scene_get_cull_nodes(s: *const trt_scene, bbox6: *mut f32, prim: *mut i32, skip: *mut i32, cap: u32) -> c_int;
+    pub fn trt_scene_get_compact_nodes(s: *const trt_scene, words4: *mut u32, cap: u32) -> c_int;
 
     pub fn trt_camera_init(out: *mut trt_camera, focus_distance: f32, defocus_angle_deg: f32, position: trt_vec3,
                            look_at: trt_vec3, up: trt_vec3, vertical_fov_deg: f32, width: u32, height: u32) -> c_int;

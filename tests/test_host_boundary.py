@@ -216,3 +216,51 @@ def test_cpp_image_save_writes_a_valid_png(trt, tmp_path, size):
     assert got.shape == (h, w, 3) and np.array_equal(got, want)
     assert np.array_equal(np.asarray(PILImage.open(ppm).convert("RGB")), want)
     assert want[..., 1].max() == 254 and want[0, 0, 2] == 0
+
+
+def test_compact_nodes_are_the_culling_tree_rounded_outward(trt):
+    """Scenes walked from global memory carry the culling tree as 16-byte nodes with f16 boxes.  The walk stays exact
+    only if every f16 box CONTAINS the f32 box (then it passes whenever the exact box passes); it stays cheap if each
+    bound is the nearest such f16.  Links: an inner node's skip, a leaf's sequence number."""
+    desc = trt.scenes.sphere_grid(3000, 64, 36)                              # hot part > 64 KB
+    pw, _ = trt.world_from_description(desc)
+    sc = pw.get_bvh()
+    assert sc.info()["lds_bytes"] == 0
+    lo16, hi16, link = sc.compact_nodes()
+    box, prim, skip = sc.cull_nodes()
+    lo32, hi32 = box[:, :3], box[:, 3:]
+    lo, hi = lo16.astype(np.float32), hi16.astype(np.float32)
+    assert (lo <= lo32).all() and (hi >= hi32).all()
+    # tightest: one f16 step inwards would cut into the exact box
+    assert (np.nextafter(lo16, np.float16(np.inf)).astype(np.float32) > lo32).all()
+    assert (np.nextafter(hi16, np.float16(-np.inf)).astype(np.float32) < hi32).all()
+    leaf = prim >= 0
+    assert ((link & 0x80000000) != 0).tolist() == leaf.tolist()
+    assert np.array_equal(link[~leaf], skip[~leaf].astype(np.uint32))
+    assert np.array_equal(link[leaf] & 0x7FFFFFFF, np.arange(leaf.sum(), dtype=np.uint32))
+    # a scene that fits LDS has no such array
+    small, _ = trt.world_from_description(trt.scenes.cornell())
+    assert small.get_bvh().compact_nodes() is None
+
+
+def test_f16_outward_rounding_handles_the_edges(trt, monkeypatch):
+    """Coordinates beyond the f16 range, zeros, subnormals and exact f16 values (TRT_COMPACT_NODES=1 forces the array
+    for a small scene)."""
+    monkeypatch.setenv("TRT_COMPACT_NODES", "1")
+    mats = [("m", 0, (0.5, 0.5, 0.5), 0.0)]
+    geos = [("sphere", (1.0e5, 0.0, 0.0), 1.0, "m"), ("sphere", (-7.0e4, 3.0e-6, -3.0e-6), 0.5, "m"),
+            ("sphere", (0.5, 2.0, -1.0), 0.25, "m"), ("sphere", (1.0e-7, -1.0e-7, 0.0), 1.0e-7, "m"),
+            ("quad", (0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), "m"), ("sphere", (65504.0, -65504.0, 2049.0), 1.0, "m")]
+    cam = dict(focus_distance=1.0, defocus_angle=0.0, position=(0.0, 0.0, 5.0), look_at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
+               vertical_fov=40.0, width=8, height=8)
+    pw, _ = trt.world_from_description(dict(name="edges", materials=mats, geometries=geos, camera=cam, background=(0, 0, 0)))
+    sc = pw.get_bvh()
+    lo16, hi16, _ = sc.compact_nodes()
+    box, _, _ = sc.cull_nodes()
+    lo, hi = lo16.astype(np.float32), hi16.astype(np.float32)
+    assert (lo <= box[:, :3]).all() and (hi >= box[:, 3:]).all()
+    assert np.isinf(hi).any() and np.isinf(lo).any()                             # beyond 65504: the conservative infinity
+    fin = np.isfinite(lo) & np.isfinite(hi)
+    with np.errstate(over="ignore"):
+        assert (np.nextafter(lo16, np.float16(np.inf)).astype(np.float32)[fin] > box[:, :3][fin]).all()
+        assert (np.nextafter(hi16, np.float16(-np.inf)).astype(np.float32)[fin] < box[:, 3:][fin]).all()

@@ -89,6 +89,7 @@ SIGNATURES = {
     "trt_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
     "trt_scene_get_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "trt_scene_get_cull_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
+    "trt_scene_get_compact_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32]),
     "trt_camera_init": (C.c_int, [C.POINTER(CameraPOD), C.c_float, C.c_float, Vec3, Vec3, Vec3, C.c_float,
                                   C.c_uint32, C.c_uint32]),
     "trt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),

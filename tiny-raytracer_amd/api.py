@@ -88,6 +88,19 @@ class Scene:
         return self._dump(lib.trt_scene_get_cull_nodes, self.info()["num_cull_nodes"])
 
 
+    def compact_nodes(self):
+        """The culling tree as 16-byte nodes (f16 boxes rounded outward) if the scene is walked from global memory:
+        (lo[n,3] float16, hi[n,3] float16, link[n] uint32), else None."""
+        n = self.info()["num_cull_nodes"]
+        words = np.zeros((n, 4), np.uint32)
+        rc = lib.trt_scene_get_compact_nodes(self._h, words.ctypes.data, n)
+        if rc == _lib.ERR_NOT_FOUND:
+            return None
+        check(rc)
+        h = words[:, :3].copy().view(np.float16).reshape(n, 6)
+        return h[:, :3], h[:, 3:], words[:, 3].copy()
+
+
 class World:
     def __init__(self):
         self._h = C.c_void_p()

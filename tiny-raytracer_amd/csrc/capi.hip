@@ -9,6 +9,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <new>
@@ -306,6 +307,15 @@ int trt_scene_get_nodes(const trt_scene* s, float* bbox6, int32_t* prim, int32_t
 int trt_scene_get_cull_nodes(const trt_scene* s, float* bbox6, int32_t* prim, int32_t* skip, uint32_t cap) {
     if (!s || !bbox6 || !prim || !skip) return fail(TRT_ERR_INVALID_ARG, "null argument");
     return copy_nodes(s->host.culling, bbox6, prim, skip, cap);
+}
+
+int trt_scene_get_compact_nodes(const trt_scene* s, uint32_t* words4, uint32_t cap) {
+    if (!s || !words4) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    const SceneLayout& L = s->host.layout;
+    if (L.off_compact == 0u) return fail(TRT_ERR_NOT_FOUND, "scene has no compact node array (it is walked from LDS)");
+    if (cap < L.n_cull_nodes) return fail(TRT_ERR_INVALID_ARG, "buffer too small");
+    memcpy(words4, s->host.blob.data() + 16u * (size_t)L.off_compact, 16u * (size_t)L.n_cull_nodes);
+    return TRT_OK;
 }
 
 // ---- Camera ----

@@ -45,9 +45,8 @@ inline uint32_t rng_seed_key(uint32_t seed) {
 enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE,
        CTR_W_ROUNDS = 8, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_COUNT = 16 };
 
-// Largest hot blob (SceneLayout::hot_bytes) copied whole into LDS, once per workgroup; larger scenes keep only
-// the culling tree's top levels there.
-constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
+// scene.h kLdsSceneMaxBytes: hot blobs up to that size are copied whole into LDS; larger scenes keep only the culling
+// tree's top levels there (TRT_TOP_NODES) or nothing.
 inline int scene_mode(const SceneLayout& L) { return L.hot_bytes <= kLdsSceneMaxBytes ? 1 : (L.n_top_nodes > 0 ? 2 : 0); }
 inline uint32_t scene_lds_bytes(const SceneLayout& L) { int m = scene_mode(L); return m == 1 ? L.hot_bytes : (m == 2 ? 32u * L.n_top_nodes : 0u); }
 

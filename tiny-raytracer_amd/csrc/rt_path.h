@@ -306,6 +306,51 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
     } while (i < n);
 }
 
+// Scenes too large for LDS are bound by the vector-memory front end, not by arithmetic: every box step of every lane is
+// two divergent 16-byte loads (100 k spheres: 9.96 G wave loads per launch, one per 28 cycles per CU, VALU 35 % busy).
+// walk_compact steps a 16-BYTE node instead - the culling tree's boxes rounded OUTWARD to f16, one load per step, half
+// the tree's footprint (3 MB: it now fits one XCD's L2).  Legal because the hierarchy only has to be conservative
+// (DESIGN.md 4.1): a box that contains the exact box passes whenever the exact box does (same slab arithmetic, monotonic
+// rounding), so no leaf the reference reaches is skipped; and a leaf whose coarse box passes is put aside and, at its
+// turn, tested against its EXACT f32 box with the current t_best - the reference's own leaf-box test - before its
+// primitive is touched.  An inner node's first child is the next node (pre-order), so its fourth word is the skip
+// link; a leaf's is LEAF | its sequence number in the leaf list (exact box + primitive reference).
+constexpr uint32_t kCompactLeafBit = 0x80000000u;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+
+template <int MODE, bool STATS>
+TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
+                          const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
+    const uint32_t n = sc.L.n_cull_nodes;
+    for (;;) {
+        uint32_t cnt = 0;
+        while (tr.i < n && cnt < slots) {
+            const uint4 q = nodes16[tr.i];
+            if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+            const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
+            const bool pass = slab_fast6(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), ray.o, tr.inv,
+                                         kTMin, tr.t_best);
+            const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
+            const uint32_t next = tr.i + 1u;                                         // first child, or a leaf's successor
+            if (pass && is_leaf) {
+                stk[64u * cnt] = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), 0.0f);
+                cnt++;
+            }
+            tr.i = (pass || is_leaf) ? next : q.w;
+        }
+        if (cnt == 0u) break;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t leaf = __float_as_uint(stk[64u * k].x);
+            const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
+            if constexpr (STATS) ctr.node++;
+            if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) {                  // the reference's leaf-box test, at the leaf's turn
+                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+                trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
+            }
+        }
+    }
+}
+
 constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)
 
 // Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  Postponed leaves go to
@@ -313,10 +358,12 @@ constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf
 // `leaf_slots` = 4 (also for 0 = default), 2 or 1 (tuning and tests; wave-uniform).
 template <int MODE, bool STATS>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
-                             uint32_t leaf_slots = 4u, float2* lds_stack = nullptr, const float4* __restrict__ leaf_list = nullptr) {
+                             uint32_t leaf_slots = 4u, float2* lds_stack = nullptr, const float4* __restrict__ leaf_list = nullptr,
+                             const uint4* __restrict__ nodes16 = nullptr) {
     Trav tr = trav_begin(sc, ray, ref_tree);
     if (__builtin_expect(!tr.ref, 1)) {
-        if (lds_stack != nullptr && leaf_list != nullptr) walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+        if (lds_stack != nullptr && nodes16 != nullptr) walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+        else if (lds_stack != nullptr && leaf_list != nullptr) walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
         else if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
         else if (leaf_slots >= 4u || leaf_slots == 0u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
         else if (leaf_slots >= 2u) walk_fast<MODE, STATS, 2>(sc, ray, tr, ctr);

@@ -66,6 +66,8 @@ struct World {
 //   [sphere_material: ns] u32   [material_kind: nm] u32          (padded to 16 bytes)   <- hot_bytes end here
 //   [reference nodes: 2n] same node format
 //   [leaf list: 2 per leaf] the leaves of the trees in walk order, same node format (skip = successor)
+//   [compact culling tree: 1 per node] scenes too large for LDS only: (f16 lo.xy | lo.z,hi.x | hi.yz | skip or LEAF|k),
+//       boxes rounded OUTWARD to f16, pre-order (an inner node's first child is the next node)
 struct SceneLayout {
     uint32_t n_nodes;           // reference tree (2N-1)
     uint32_t n_cull_nodes;      // culling tree
@@ -79,7 +81,10 @@ struct SceneLayout {
     uint32_t n_leaves;          // leaves of either tree (= primitives), in walk order
     uint32_t off_leaf_list;     // in 16-byte elements: the leaves alone, node format, skip = successor (cold part of the blob)
     uint32_t flat_walk;         // 1: few enough leaves that the streamed kernel steps the leaf list in lock-step (rt_path.h walk_flat)
+    uint32_t off_compact;       // in 16-byte elements: the culling tree as 16-byte nodes (f16 boxes rounded outward), pre-order; 0 = absent
 };
+// Largest hot blob (SceneLayout::hot_bytes) copied whole into LDS, once per workgroup; larger scenes are read from global memory.
+constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
 constexpr uint32_t kFlatWalkMaxLeaves = 32;   // at most this many primitives: lock-step leaf list instead of the culling tree
 
 struct NodeDump {                            // pre-order inspection copy of one tree

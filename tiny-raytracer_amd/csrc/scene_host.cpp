@@ -109,6 +109,51 @@ inline double surface_area(const Box& b) {
 // SA(left)*n_left + SA(right)*n_right is smallest; an inner node whose box is at least `kPrune` of its nearest
 // emitted ancestor's is not emitted at all (its children hang directly off that ancestor), since a ray that
 // passed the ancestor almost surely passes it too.  Boxes are exact f32 unions of leaf boxes.
+// f32 -> f16 bits rounded toward -inf (up = false) or +inf (up = true): the nearest-even conversion, stepped by one
+// f16 if it landed on the wrong side.  |x| beyond the f16 range becomes +-inf or +-65504, whichever is conservative.
+float f16_bits_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1Fu, m = h & 0x3FFu;
+    uint32_t out;
+    if (e == 0u) {
+        if (m == 0u) out = sign;
+        else {                                              // subnormal: m * 2^-24
+            float v = (float)m * 5.9604644775390625e-08f;
+            uint32_t b; memcpy(&b, &v, 4); out = b | sign;
+        }
+    } else if (e == 31u) out = sign | 0x7F800000u | (m << 13);
+    else out = sign | ((e + 112u) << 23) | (m << 13);
+    float f; memcpy(&f, &out, 4); return f;
+}
+uint16_t f32_to_f16_nearest(float x) {
+    uint32_t b; memcpy(&b, &x, 4);
+    const uint32_t sign = (b >> 16) & 0x8000u;
+    const uint32_t a = b & 0x7FFFFFFFu;
+    if (a >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | (a > 0x7F800000u ? 0x200u : 0u));
+    if (a >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);            // >= 65520 rounds to inf
+    if (a < 0x33000001u) return (uint16_t)sign;                           // <= 2^-25 rounds to zero
+    int32_t e = (int32_t)(a >> 23) - 127;
+    uint32_t m = (a & 0x7FFFFFu) | 0x800000u;
+    uint32_t shift = e < -14 ? (uint32_t)(13 + (-14 - e)) : 13u;          // subnormal results lose more bits
+    uint32_t half = m >> shift, rem = m & ((1u << shift) - 1u), mid = 1u << (shift - 1u);
+    if (rem > mid || (rem == mid && (half & 1u))) half++;
+    uint32_t he = e < -14 ? 0u : (uint32_t)(e + 15);
+    uint32_t out = e < -14 ? half : ((he << 10) + (half - 0x400u));       // a mantissa carry rolls into the exponent
+    return (uint16_t)(sign | out);
+}
+uint16_t f32_to_f16_dir(float x, bool up) {
+    if (x != x) return up ? 0x7C00u : 0xFC00u;                            // NaN: the conservative infinity
+    uint16_t h = f32_to_f16_nearest(x);
+    const float back = f16_bits_to_f32(h);
+    if (up ? back >= x : back <= x) return h;
+    // step one f16 toward the wanted side
+    if (up) {
+        if (h & 0x8000u) return (h & 0x7FFFu) == 0u ? (uint16_t)0x0001u : (uint16_t)(h - 1u);   // negative: smaller magnitude
+        return (uint16_t)(h + 1u);                                                           // positive: larger magnitude (0x7BFF -> inf)
+    }
+    if (h & 0x8000u) return (uint16_t)(h + 1u);
+    return (h & 0x7FFFu) == 0u ? (uint16_t)0x8001u : (uint16_t)(h - 1u);
+}
+
 struct CullBuilder {
     double kPrune = 0.7;                     // measured best on MI355X (0.5-0.9 within 3 %); env TRT_CULL_PRUNE overrides (tuning; any value gives the same hits)
     const std::vector<Box>& leaf_box;        // leaf k of the reference tree, in left-first order
@@ -258,6 +303,13 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     L.n_leaves = (uint32_t)leaf_box.size();
     L.off_leaf_list = L.off_ref_nodes + 2u * nn;
     L.blob_bytes = L.hot_bytes + 32u * nn + 32u * L.n_leaves;
+    L.off_compact = 0u;
+    bool want_compact = L.hot_bytes > kLdsSceneMaxBytes;                      // scenes walked from global memory
+    if (const char* e = getenv("TRT_COMPACT_NODES")) want_compact = atoi(e) != 0;             // tuning / tests; same frames either way
+    if (want_compact) {
+        L.off_compact = L.blob_bytes / 16u;
+        L.blob_bytes += 16u * nc;
+    }
     L.all_finite = all_finite ? 1u : 0u;
     L.flat_walk = L.n_leaves <= kFlatWalkMaxLeaves ? 1u : 0u;
     if (const char* e = getenv("TRT_FLAT_WALK")) L.flat_walk = atoi(e) ? 1u : 0u;            // tuning / tests; same frames either way
@@ -321,6 +373,23 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
         std::vector<uint32_t> lplace(nl);
         for (uint32_t k = 0; k < nl; k++) { lskip[k] = (int32_t)k + 1; lplace[k] = k; }
         pack_nodes(f4 + L.off_leaf_list, leaf_box, lprim, lskip, lplace);
+    }
+    if (L.off_compact) {   // compact culling tree: f16 boxes rounded outward (any superset box keeps the hits: DESIGN.md 4.1), pre-order
+        uint32_t* c = u32 + 4u * (size_t)L.off_compact;
+        std::vector<int32_t> leaf_seq(nc, -1);
+        {
+            int32_t k = 0;
+            for (uint32_t i = 0; i < nc; i++) if (cb.node_leaf[i] >= 0) leaf_seq[i] = k++;
+        }
+        for (uint32_t i = 0; i < nc; i++) {
+            const Box& bx = cb.node_box[i];
+            const uint32_t lx = f32_to_f16_dir(bx.lo.x, false), ly = f32_to_f16_dir(bx.lo.y, false), lz = f32_to_f16_dir(bx.lo.z, false);
+            const uint32_t hx = f32_to_f16_dir(bx.hi.x, true), hy = f32_to_f16_dir(bx.hi.y, true), hz = f32_to_f16_dir(bx.hi.z, true);
+            c[4 * i + 0] = lx | ly << 16;
+            c[4 * i + 1] = lz | hx << 16;
+            c[4 * i + 2] = hy | hz << 16;
+            c[4 * i + 3] = cb.node_leaf[i] >= 0 ? (0x80000000u | (uint32_t)cb.node_leaf[i]) : (uint32_t)cb.node_skip[i];
+        }
     }
     dump_tree(out.reference, b.node_box, b.node_prim, b.node_skip);
     dump_tree(out.culling, cb.node_box, cull_prim_geo, cb.node_skip);
