@@ -180,9 +180,12 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     const size_t scene_bytes = scene_lds_bytes(sc.L);
     const int mode = scene_mode(sc.L);
     // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies, 512-lane workgroups sharing a big
-    // LDS copy between 8 waves, 5 waves per SIMD for scenes read from global memory
+    // LDS copy between 8 waves, 8 waves per SIMD for scenes read from global memory
     const int threads = (mode == MODE_LDS && sc.L.hot_bytes > 20u * 1024u) ? 512 : 256;
-    int w = mode == MODE_LDS ? 6 : 5;            // 6 waves per SIMD (80 VGPRs, 21 spilled) beat 7 (72 VGPRs, 38 spilled) by 3 % and 5 (no spills) by 2 % on Cornell
+    // LDS scenes: 6 waves per SIMD (80 VGPRs, 21 spilled) beat 7 (72 VGPRs, 38 spilled) by 3 % and 5 (no spills) by 2 % on
+    // Cornell.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box step once the
+    // compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6, 2.29 at 8)
+    int w = mode == MODE_LDS ? 6 : 8;
     if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
     if (w < 5) w = 5;
     if (threads == 512 && w > 6) w = 6;
@@ -246,7 +249,12 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                 else e = launch_pick<MODE_LDS, 5, 256>(stats, go);
                 break;
             case MODE_HYBRID: e = launch_pick<MODE_HYBRID, 1, 256>(stats, go); break;
-            default: e = launch_pick<MODE_GLOBAL, 1, 256>(stats, go); break;
+            default:
+                if (w >= 8) e = launch_pick<MODE_GLOBAL, 8, 256>(stats, go);
+                else if (w >= 7) e = launch_pick<MODE_GLOBAL, 7, 256>(stats, go);
+                else if (w >= 6) e = launch_pick<MODE_GLOBAL, 6, 256>(stats, go);
+                else e = launch_pick<MODE_GLOBAL, 1, 256>(stats, go);
+                break;
         }
         if (e != hipSuccess) return e;
         const uint32_t fold_blocks = (uint32_t)((n_pixels + 255ull) / 256ull);
