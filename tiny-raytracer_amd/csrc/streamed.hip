@@ -190,15 +190,15 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     if (w < 5) w = 5;
     if (threads == 512 && w > 6) w = 6;
     uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
-    // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
-    // resident workgroup (random-spheres: 49.6 KB scene copy, 3 workgroups of 512 lanes per CU without it, 2 with it:
-    // measured 7 % slower than register slots); otherwise the slots are registers
     // slots of the LDS stack: 4 for tree walks; 6 for the lock-step leaf list, whose t_best stays stale for a whole walk
     // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12)
     const bool flat = sc.L.flat_walk && !ra_all.ref_tree;
     const uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 6u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
     const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
     const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
+    // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
+    // resident workgroup (random-spheres: 49.6 KB scene copy, 3 workgroups of 512 lanes per CU without it, 2 with it:
+    // measured 7 % slower than register slots); otherwise the slots are registers
     bool lds_stack = ra_all.lds_leaf_stack != 0u;
     if (lds_stack && ra_all.lds_leaf_stack != 2u) {
         const uint32_t fit_plain = scene_bytes ? (uint32_t)(160u * 1024u / scene_bytes) : wg_per_cu;
