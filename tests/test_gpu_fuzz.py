@@ -100,3 +100,31 @@ def test_walk_schedules_agree_on_many_rays(trt, monkeypatch, seed):
         assert_bit_equal(img.data, ref_img, f"{desc['name']} backend {backend} slots {slots} lds {lds}")
         for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
             assert st[k] == ref_stats[k], (backend, slots, lds, k)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_compact_node_walk_agrees_on_many_rays(trt, monkeypatch, seed):
+    """Scenes walked from global memory (hot part > 64 KB), ~10^8 rays: the 16-byte-node walk (f16 boxes, exact leaf
+    boxes re-tested) against the 32-byte-node walk, the plain one-slot walk and the megakernel - frames, ray counts and
+    primitive-test counters."""
+    desc = random_scene(500 + seed, n_prims=2600 + 900 * seed, width=1280, height=800)
+    ref_img = ref_stats = None
+    for backend, compact, slots in ((3, "0", "1"), (3, "1", None), (3, "0", None), (3, "1", "2"), (0, "0", None)):
+        monkeypatch.setenv("TRT_COMPACT_NODES", compact)                            # read when the scene is compiled
+        if slots is None:
+            monkeypatch.delenv("TRT_LEAF_SLOTS", raising=False)
+        else:
+            monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
+        pw, pcam = trt.world_from_description(desc)
+        assert pw.get_bvh().info()["lds_bytes"] == 0
+        assert (pw.get_bvh().compact_nodes() is not None) == (compact == "1")
+        r = trt.Renderer(16, 1, 16, False, desc["background"], seed=13, backend=backend)
+        img = r.render(pcam, pw, collect_stats=2)
+        st = dict(r.last_stats)
+        plain = r.render(pcam, pw)                                                   # production kernel
+        if ref_img is None:
+            ref_img, ref_stats = img.data.copy(), st
+        assert_bit_equal(img.data, ref_img, f"{desc['name']} counting, backend {backend} compact {compact} slots {slots}")
+        assert_bit_equal(plain.data, ref_img, f"{desc['name']} backend {backend} compact {compact} slots {slots}")
+        for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
+            assert st[k] == ref_stats[k], (backend, compact, slots, k)
