@@ -1,0 +1,159 @@
+/* Empirical check (test infrastructure, links the CPU oracle) of the statement DESIGN.md section 10 builds the planned
+ * near-first traversal on:
+ *
+ *   Let t_k be primitive k's own hit distance on [t_min, inf) (its "intrinsic" t; none if it misses), m the primitive
+ *   with the smallest t_k, ties going to the one that comes first in the reference's left-first leaf order, and
+ *   start_m the entry of m's leaf box under the reference's slab arithmetic.  If t_m >= start_m ("the winner is
+ *   safe"), the reference's fixed-order BVH walk (bvh.rs:88-107) returns exactly m with exactly t_m - whatever the
+ *   other primitives, their boxes and the hierarchy above them look like.
+ *
+ * So ANY traversal order that finds that arg-min is exact, provided it falls back to the fixed-order walk for the
+ * (rare) rays whose winner is not safe.  This program measures both: mismatches among safe winners (must be 0) and
+ * how rare unsafe winners are.
+ *   ordered_theorem_check <rays per scene>
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "rt_oracle.h"
+
+typedef struct { int kind; orc_vec3 a, b, c; float r; } prim_t;          /* kind 0 sphere (a = centre), 1 quad (a corner, b u, c v) */
+
+static uint64_t g_state = 0x9E3779B97F4A7C15ull;
+static double urand(void) {
+    g_state ^= g_state >> 12; g_state ^= g_state << 25; g_state ^= g_state >> 27;
+    return (double)((g_state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0;
+}
+static float frand(float lo, float hi) { return (float)(lo + (hi - lo) * urand()); }
+static orc_vec3 v3(float x, float y, float z) { orc_vec3 v = {x, y, z}; return v; }
+
+static int check_scene(const char *name, const prim_t *prims, int n, float extent, long n_rays, int on_surface) {
+    orc_world *w = orc_world_new();
+    char mname[32];
+    for (int i = 0; i < n; i++) {
+        snprintf(mname, sizeof mname, "m%d", i);
+        int mi = orc_world_add_material(w, mname, 0, v3(0.5f, 0.5f, 0.5f), 0.0f);     /* material index identifies the primitive */
+        if (prims[i].kind == 0) orc_world_add_sphere(w, prims[i].a, prims[i].r, mi);
+        else orc_world_add_quad(w, prims[i].a, prims[i].b, prims[i].c, mi);
+    }
+    orc_world_build(w);
+    const int cap = 2 * n;
+    float *bbox = malloc(sizeof(float) * 6 * cap);
+    int32_t *prim = malloc(sizeof(int32_t) * cap), *sub = malloc(sizeof(int32_t) * cap);
+    const int nn = orc_world_bvh_dump(w, bbox, prim, sub, cap);
+    int *order = malloc(sizeof(int) * n);             /* left-first leaf order */
+    orc_aabb *lbox = malloc(sizeof(orc_aabb) * n);
+    int nl = 0;
+    for (int i = 0; i < nn; i++)
+        if (prim[i] >= 0) {
+            order[nl] = prim[i];
+            memcpy(&lbox[nl], bbox + 6 * i, sizeof(float) * 6);
+            nl++;
+        }
+    long hits = 0, unsafe = 0, unsafe_differs = 0, bad = 0, ties = 0;
+    for (long r = 0; r < n_rays; r++) {
+        orc_vec3 o, d;
+        if (on_surface && (r & 1)) {                  /* leave from a point on a primitive: grazing and self-hit cases */
+            const prim_t *p = &prims[(int)(urand() * n) % n];
+            if (p->kind == 0) {
+                orc_vec3 u = v3(frand(-1, 1), frand(-1, 1), frand(-1, 1));
+                float l = sqrtf(u.x * u.x + u.y * u.y + u.z * u.z) + 1e-20f;
+                o = v3(p->a.x + p->r * u.x / l, p->a.y + p->r * u.y / l, p->a.z + p->r * u.z / l);
+            } else {
+                float s = frand(0, 1), t = frand(0, 1);
+                o = v3(p->a.x + s * p->b.x + t * p->c.x, p->a.y + s * p->b.y + t * p->c.y, p->a.z + s * p->b.z + t * p->c.z);
+            }
+        } else {
+            o = v3(frand(-extent, extent), frand(-extent, extent), frand(-extent, extent));
+        }
+        d = v3(frand(-1, 1), frand(-1, 1), frand(-1, 1));
+        if ((r % 16) == 3) d.x = 0.0f;                /* axis-parallel rays: the reference's NaN-prone slab cases */
+        if ((r % 64) == 7) { d.y = 0.0f; d.z = (r & 128) ? 1.0f : -1.0f; }
+        if (d.x == 0.0f && d.y == 0.0f && d.z == 0.0f) d.z = 1.0f;
+        orc_ray ray = orc_ray_new(o, d);
+        orc_hit_record ref;
+        const int ref_hit = orc_world_hit(w, &ray, 0.001f, INFINITY, &ref, NULL);
+        int m = -1, m_slot = -1;
+        float tm = INFINITY;
+        for (int k = 0; k < nl; k++) {                /* walk order, strict '<': the first of equal t stays */
+            const prim_t *p = &prims[order[k]];
+            orc_hit_record h;
+            int ok = p->kind == 0 ? orc_sphere_hit(p->a, p->r, &ray, 0.001f, INFINITY, &h) : orc_quad_hit(p->a, p->b, p->c, &ray, 0.001f, INFINITY, &h);
+            if (!ok) continue;
+            if (h.t == tm) ties++;
+            if (h.t < tm) { tm = h.t; m = order[k]; m_slot = k; }
+        }
+        if (m < 0) {
+            if (ref_hit) { bad++; if (bad < 5) fprintf(stderr, "%s: reference hits where no primitive does\n", name); }
+            continue;
+        }
+        hits++;
+        const int safe = orc_aabb_intersect(&lbox[m_slot], &ray, 0.001f, nextafterf(tm, INFINITY));
+        const int same = ref_hit && ref.t == tm && ref.material == m;
+        if (safe) {
+            if (!same) { bad++; if (bad < 5) fprintf(stderr, "%s: safe winner %d t=%.9g but reference %s t=%.9g prim %d\n", name, m, tm, ref_hit ? "hit" : "miss", ref.t, ref.material); }
+        } else {
+            unsafe++;
+            if (!same) unsafe_differs++;
+        }
+    }
+    printf("%-16s %5d prims %9ld rays: %9ld hits, %6ld exact-t ties, unsafe winners %ld (%.2e of hits; reference differs for %ld), safe mismatches %ld\n",
+           name, n, n_rays, hits, ties, unsafe, hits ? (double)unsafe / hits : 0.0, unsafe_differs, bad);
+    orc_world_free(w);
+    free(bbox); free(prim); free(sub); free(order); free(lbox);
+    return bad != 0;
+}
+
+int main(int argc, char **argv) {
+    const long n_rays = argc > 1 ? atol(argv[1]) : 200000;
+    int fail = 0;
+    {   /* Cornell box (src/main.rs:29-125): coplanar light and ceiling = exact ties */
+        prim_t p[18]; int n = 0;
+        #define Q(cx, cy, cz, ux, uy, uz, vx, vy, vz) p[n].kind = 1, p[n].a = v3(cx, cy, cz), p[n].b = v3(ux, uy, uz), p[n].c = v3(vx, vy, vz), n++
+        Q(100, 0, 0, 0, 100, 0, 0, 0, 100); Q(0, 0, 0, 0, 100, 0, 0, 0, 100); Q(65, 100, 60, -30, 0, 0, 0, 0, -20);
+        Q(0, 0, 0, 100, 0, 0, 0, 0, 100); Q(100, 100, 100, -100, 0, 0, 0, 0, -100); Q(0, 0, 100, 100, 0, 0, 0, 100, 0);
+        const float bx[2][6] = {{25, 0, 50, 55, 60, 80}, {45, 0, 10, 75, 30, 40}};
+        for (int b = 0; b < 2; b++) {
+            const float x0 = bx[b][0], y0 = bx[b][1], z0 = bx[b][2], x1 = bx[b][3], y1 = bx[b][4], z1 = bx[b][5];
+            Q(x0, y0, z1, x1 - x0, 0, 0, 0, y1 - y0, 0); Q(x1, y0, z1, 0, 0, z0 - z1, 0, y1 - y0, 0); Q(x1, y0, z0, x0 - x1, 0, 0, 0, y1 - y0, 0);
+            Q(x0, y0, z0, 0, 0, z1 - z0, 0, y1 - y0, 0); Q(x0, y1, z1, x1 - x0, 0, 0, 0, 0, z0 - z1); Q(x0, y0, z0, x1 - x0, 0, 0, 0, 0, z1 - z0);
+        }
+        for (int i = 0; i < n; i++) p[i].r = 0;
+        fail |= check_scene("cornell", p, n, 100.0f, n_rays, 1);
+        /* origins inside the room only (the distribution the renderer produces) */
+        fail |= check_scene("cornell-inside", p, n, 50.0f, n_rays, 1);
+    }
+    {   /* overlapping random spheres and quads */
+        const int n = 300; prim_t *p = calloc(n, sizeof *p);
+        for (int i = 0; i < n; i++) {
+            p[i].kind = i & 1;
+            p[i].a = v3(frand(-4, 4), frand(-4, 4), frand(-4, 4));
+            if (p[i].kind == 0) p[i].r = frand(0.2f, 1.5f);
+            else { p[i].b = v3(frand(-2, 2), frand(-2, 2), frand(-2, 2)); p[i].c = v3(frand(-2, 2), frand(-2, 2), frand(-2, 2)); }
+        }
+        fail |= check_scene("mixed-overlap", p, n, 6.0f, n_rays, 1);
+        free(p);
+    }
+    {   /* touching spheres on a grid (tangent contacts, grazing hits) + a huge ground sphere */
+        const int side = 24, n = side * side + 1; prim_t *p = calloc(n, sizeof *p);
+        for (int i = 0; i < side; i++) for (int j = 0; j < side; j++) { prim_t *q = &p[i * side + j]; q->kind = 0; q->a = v3(0.4f * i - 4.8f, 0.2f, 0.4f * j - 4.8f); q->r = 0.2f; }
+        p[n - 1].kind = 0; p[n - 1].a = v3(0, -1000, 0); p[n - 1].r = 1000;
+        fail |= check_scene("touching-grid", p, n, 6.0f, n_rays, 1);
+        free(p);
+    }
+    {   /* coincident and nested primitives: equal t from different primitives everywhere */
+        const int n = 40; prim_t *p = calloc(n, sizeof *p);
+        for (int i = 0; i < n; i++) {
+            p[i].kind = (i / 2) & 1;
+            p[i].a = v3((float)((i / 4) % 3) - 1.0f, (float)((i / 12) % 2), 0.0f);      /* four copies of everything */
+            if (p[i].kind == 0) p[i].r = 0.75f;
+            else { p[i].b = v3(1.5f, 0, 0); p[i].c = v3(0, 1.5f, 0); }
+        }
+        fail |= check_scene("coincident", p, n, 3.0f, n_rays, 1);
+        free(p);
+    }
+    return fail;
+}
