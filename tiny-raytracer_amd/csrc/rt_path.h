@@ -351,6 +351,92 @@ TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
     }
 }
 
+// A primitive's own hit distance on [kTMin, limit): what Sphere::hit / Quad::hit return for that interval, without
+// touching the walk's state.  Returns false on a miss.
+template <int MODE, bool STATS>
+TRT_DEV bool leaf_hit_t(const SceneAcc<MODE>& sc, const Ray& ray, uint32_t leaf, float limit, float& t_out, Counters<STATS>& ctr) {
+    const uint32_t idx = leaf & PRIM_INDEX_MASK;
+    if (leaf & PRIM_QUAD_BIT) {                                        // Quad::hit, quad.rs:33-54
+        if constexpr (STATS) ctr.quad_plane++;
+        float4 q0 = sc.quad(0, idx);
+        V3 nrm = v3(q0.x, q0.y, q0.z);
+        float dir_norm = dot(ray.d, nrm);
+        float t = (q0.w - dot(ray.o, nrm)) / dir_norm;
+        if (!(kTMin <= t && t < limit)) return false;
+        if constexpr (STATS) ctr.quad_inside++;
+        float4 q1 = sc.quad(1, idx), q2 = sc.quad(2, idx), q3 = sc.quad(3, idx), q4 = sc.quad(4, idx);
+        V3 p = ray_at(ray, t) - v3(q1.x, q1.y, q1.z);
+        V3 vv = v3(q2.x, q2.y, q2.z), ww = v3(q2.w, q3.x, q3.y), uu = v3(q3.z, q3.w, q4.x);
+        float planar_x = dot(cross(p, vv), ww);
+        float planar_y = dot(cross(uu, p), ww);
+        if (!(0.0f <= planar_x && planar_x < 1.0f && 0.0f <= planar_y && planar_y < 1.0f)) return false;
+        t_out = t;
+        return true;
+    }
+    if constexpr (STATS) ctr.sphere++;
+    return sphere_test(sc.sphere(idx), ray, kTMin, limit, t_out);      // Sphere::hit, sphere.rs:29-54
+}
+
+// EXPERIMENTAL (opt-in, TRT_ORDERED_WALK=1): near-first walk for scenes in global memory.
+// Known gap: a true winner that is itself unsafe (own t below its box entry) can be culled by a slightly farther
+// candidate before it is ever tested, so the safe-winner check never sees it: 48 of 2.6e7 rays differ on the 100 k
+// touching-spheres scene.  The fixed-order walks stay the default.  `nodes16` is this ray's octant array of a
+// free-order SAH tree: pre-order with the child that is nearer along the split axis first, 16-byte nodes as in
+// walk_compact.  Visiting order no longer matters for the result, because the result is defined without it:
+//   the hit is the primitive with the smallest own hit distance, ties going to the smaller leaf sequence number,
+// which IS the reference's answer whenever that winner's distance is not below the entry of its own exact leaf box
+// (tests/native/ordered_theorem_check.c), "primitive" meaning one the reference can reach at all: its exact leaf box
+// must have t_far > start (slab_leaf_candidate).  So: boxes are culled only when they start strictly beyond the best
+// distance so far (a tie may still be won on sequence), a candidate replaces the best on t < best or on equal t with a
+// smaller sequence number, and the function returns false for the (rounding-level rare) ray whose winner is unsafe -
+// the caller then re-traces it with the fixed-order walk.
+template <int MODE, bool STATS>
+TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
+                          const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
+    const uint32_t n = sc.L.n_ordered_nodes;
+    uint32_t seq_best = 0xFFFFFFFFu;
+    float start_best = 0.0f;
+    tr.i = 0u;
+    for (;;) {
+        uint32_t cnt = 0;
+        while (tr.i < n && cnt < slots) {
+            const uint4 q = nodes16[tr.i];
+            if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+            const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
+            const bool pass = slab_ge6(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), ray.o, tr.inv,
+                                       kTMin, tr.t_best);
+            const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
+            if (pass && is_leaf) {
+                stk[64u * cnt] = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), 0.0f);
+                cnt++;
+            }
+            tr.i = (pass || is_leaf) ? tr.i + 1u : q.w;
+        }
+        if (cnt == 0u) break;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t seq = __float_as_uint(stk[64u * k].x);
+            const float4 na = leaf_list[2u * seq], nb = leaf_list[2u * seq + 1u];
+            if constexpr (STATS) ctr.node++;
+            float start;
+            if (slab_leaf_candidate(na, nb, ray.o, tr.inv, kTMin, tr.t_best, start)) {     // exact leaf box: reachable, and not beyond the best
+                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+                // own hit distance up to and including the best so far (next float above it as the exclusive limit)
+                const float limit = tr.t_best < __builtin_inff() ? __uint_as_float(__float_as_uint(tr.t_best) + 1u) : tr.t_best;
+                float t;
+                if (leaf_hit_t<MODE, STATS>(sc, ray, __float_as_uint(nb.w), limit, t, ctr)) {
+                    if (t < tr.t_best || seq < seq_best) {                               // t <= t_best here; equal t: the earlier leaf wins
+                        tr.t_best = t;
+                        tr.prim_best = __float_as_uint(nb.w);
+                        seq_best = seq;
+                        start_best = start;
+                    }
+                }
+            }
+        }
+    }
+    return tr.prim_best == PRIM_NONE || tr.t_best >= start_best;                          // is the winner safe?
+}
+
 constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)
 
 // Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  Postponed leaves go to
@@ -359,10 +445,16 @@ constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf
 template <int MODE, bool STATS>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
                              uint32_t leaf_slots = 4u, float2* lds_stack = nullptr, const float4* __restrict__ leaf_list = nullptr,
-                             const uint4* __restrict__ nodes16 = nullptr) {
+                             const uint4* __restrict__ nodes16 = nullptr, const uint4* __restrict__ ordered16 = nullptr) {
     Trav tr = trav_begin(sc, ray, ref_tree);
     if (__builtin_expect(!tr.ref, 1)) {
-        if (lds_stack != nullptr && nodes16 != nullptr) walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+        if (lds_stack != nullptr && ordered16 != nullptr) {
+            const uint32_t octant = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
+            if (!walk_ordered<MODE, STATS>(sc, ordered16 + (size_t)octant * sc.L.n_ordered_nodes, leaf_list, ray, tr, ctr, lds_stack, leaf_slots)) {
+                tr = trav_begin(sc, ray, ref_tree);                                     // unsafe winner: the fixed-order walk decides
+                walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+            }
+        } else if (lds_stack != nullptr && nodes16 != nullptr) walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
         else if (lds_stack != nullptr && leaf_list != nullptr) walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
         else if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
         else if (leaf_slots >= 4u || leaf_slots == 0u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                                                                              unsigned long long* __restrict__ counters,
                                                                              uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp,
                                                                              const float4* __restrict__ leaf_list,
-                                                                             const uint4* __restrict__ nodes16) {
+                                                                             const uint4* __restrict__ nodes16,
+                                                                             const uint4* __restrict__ ordered16) {
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
     const uint32_t lane = threadIdx.x & 63u;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16);
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -212,6 +213,9 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     const bool compact = lds_stack && mode == MODE_GLOBAL && sc.L.off_compact != 0u && !ra_all.ref_tree;
     const float4* leaf_list = (lds_stack && (flat || compact)) ? sc.blob + sc.L.off_leaf_list : nullptr;
     const uint4* nodes16 = compact ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_compact) : nullptr;
+    // ... walked near-first through a free-order tree (rt_path.h walk_ordered); the compact fixed-order tree re-traces
+    // the rays whose winner is not safe
+    const uint4* ordered16 = (compact && sc.L.off_ordered != 0u) ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_ordered) : nullptr;
     if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
     const uint32_t resident = (uint32_t)cus * wg_per_cu;
     const uint32_t waves_per_wg = (uint32_t)threads / 64u;
@@ -236,7 +240,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                 if (e2 != hipSuccess) return e2;
             }
-            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches, batch_spp, leaf_list, nodes16);
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches, batch_spp, leaf_list, nodes16, ordered16);
             return hipGetLastError();
         };
         switch (mode) {
