@@ -9,7 +9,7 @@ from test_gpu_parity import STAT_KEYS, assert_bit_equal
 pytestmark = pytest.mark.gpu
 
 
-def random_scene(seed, n_prims, width=48, height=32, degenerate=False, nonfinite=False):
+def random_scene(seed, n_prims, width=48, height=32, degenerate=False, nonfinite=False, p_sphere=0.5):
     rng = np.random.default_rng(seed)
     f = lambda a: tuple(float(np.float32(v)) for v in a)
     mats = []
@@ -22,7 +22,7 @@ def random_scene(seed, n_prims, width=48, height=32, degenerate=False, nonfinite
     for i in range(n_prims):
         m = "m%d" % int(rng.integers(0, 6))
         c = rng.uniform(-4, 4, 3)
-        if rng.random() < 0.5:
+        if rng.random() < p_sphere:
             geos.append(("sphere", f(c), float(np.float32(rng.uniform(0.2, 1.5))), m))
         else:
             geos.append(("quad", f(c), f(rng.uniform(-2, 2, 3)), f(rng.uniform(-2, 2, 3)), m))
@@ -102,14 +102,14 @@ def test_walk_schedules_agree_on_many_rays(trt, monkeypatch, seed):
             assert st[k] == ref_stats[k], (backend, slots, lds, k)
 
 
-@pytest.mark.parametrize("seed", [0, 1])
-def test_global_memory_walks_agree_on_many_rays(trt, monkeypatch, seed):
-    """Scenes walked from global memory (hot part > 64 KB), ~10^8 rays: the experimental near-first walk through the
-    free-order tree (opt-in; exact on these scenes, not yet on touching spheres: DESIGN.md section 10), the fixed-order
-    16-byte-node walk (f16 boxes, exact leaf boxes re-tested), the 32-byte-node walk, the
-    plain one-slot walk and the megakernel - frames and ray counts; primitive-test counters too for the fixed-order
-    walks (the near-first walk tests other primitives on its way to the same answer)."""
-    desc = random_scene(500 + seed, n_prims=2600 + 900 * seed, width=1280, height=800)
+@pytest.mark.parametrize("spheres_only", [False, True])
+def test_global_memory_walks_agree_on_many_rays(trt, monkeypatch, spheres_only):
+    """Scenes walked from global memory (hot part > 64 KB), ~10^8 rays: the near-first walk through the free-order tree
+    (sphere-only scenes; a scene with quads ignores the request), the fixed-order 16-byte-node walk (f16 boxes, exact
+    leaf boxes re-tested), the 32-byte-node walk, the plain one-slot walk and the megakernel - frames and ray counts;
+    primitive-test counters too for the fixed-order walks (the near-first walk tests other primitives on its way to
+    the same answer)."""
+    desc = random_scene(500 + int(spheres_only), n_prims=3000, width=1280, height=800, p_sphere=1.0 if spheres_only else 0.5)
     ref_img = ref_stats = None
     for backend, compact, ordered, slots in ((3, "0", "0", "1"), (3, "1", "1", None), (3, "1", "0", None), (3, "0", "0", None),
                                             (3, "1", "1", "2"), (3, "1", "0", "2"), (0, "0", "0", None)):
@@ -131,8 +131,9 @@ def test_global_memory_walks_agree_on_many_rays(trt, monkeypatch, seed):
         tag = f"{desc['name']} backend {backend} compact {compact} ordered {ordered} slots {slots}"
         assert_bit_equal(img.data, ref_img, tag + " (counting)")
         assert_bit_equal(plain.data, ref_img, tag)
-        keys = ("samples", "rays", "shades") if ordered == "1" else ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades")
+        near_first = ordered == "1" and spheres_only and backend == 3
+        keys = ("samples", "rays", "shades") if near_first else ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades")
         for k in keys:
             assert st[k] == ref_stats[k], (tag, k)
-        if ordered == "1" and backend == 3:
-            assert st["node_tests"] < 0.6 * ref_stats["node_tests"], tag              # the point of it: far fewer box tests
+        if near_first:
+            assert st["node_tests"] < 0.7 * ref_stats["node_tests"], tag              # the point of it: far fewer box tests

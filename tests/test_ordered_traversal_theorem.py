@@ -17,10 +17,12 @@ def test_argmin_with_walk_order_ties_is_the_reference_result_when_the_winner_is_
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     rows = re.findall(r"(\S+)\s+(\d+) prims\s+(\d+) rays:\s+(\d+) hits,\s+(\d+) exact-t ties, unsafe winners (\d+) .*safe mismatches (\d+)", r.stdout)
-    assert len(rows) == 5
+    assert len(rows) == 6
     for name, _n, _rays, hits, ties, unsafe, bad in rows:
         assert int(bad) == 0, name
         assert int(hits) > 1000, name
         assert int(unsafe) <= 0.02 * int(hits), name               # the fallback must stay rare
+    m = re.search(r"worst sphere unsafety: .* = ([0-9.e+-]+), / D = ([0-9.e+-]+)", r.stdout)
+    assert m                                                                          # informative only: see the C file
     by = {row[0]: row for row in rows}
     assert int(by["cornell"][4]) > 0 and int(by["coincident"][4]) > 0          # exact ties did occur and were resolved by walk order

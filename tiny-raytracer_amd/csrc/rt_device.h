@@ -251,34 +251,6 @@ TRT_DEV bool slab_fast6(V3 lo, V3 hi, V3 o, V3 inv, float start, float end) {
     return !(end <= start);
 }
 
-// Box tests of the near-first walk (rt_path.h walk_ordered): a box is culled only if its entry lies STRICTLY beyond
-// `end`, i.e. it passes when min(end, t_far) >= start - a candidate at exactly the current best distance may still win
-// the tie on leaf order, so its box must not be dropped.
-TRT_DEV bool slab_ge6(V3 lo, V3 hi, V3 o, V3 inv, float start, float end) {
-    float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
-    float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
-    float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
-    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-    start = __builtin_fmaxf(start, tn);
-    end = __builtin_fminf(end, tf);
-    return !(end < start);
-}
-// Exact leaf box in the near-first walk.  The reference tests the leaf's primitive only if min(limit, t_far) > start
-// for its running limit; that can hold for SOME limit only if t_far > start (a ray that merely touches the box, t_far
-// == start, never reaches the primitive whatever the limit), and it can matter to the arg-min only if start is not
-// strictly beyond the best distance so far.  Both conditions; `start_out` feeds the safe-winner check.
-TRT_DEV bool slab_leaf_candidate(float4 na, float4 nb, V3 o, V3 inv, float start, float best, float& start_out) {
-    float x0 = (na.x - o.x) * inv.x, x1 = (na.w - o.x) * inv.x;
-    float y0 = (na.y - o.y) * inv.y, y1 = (nb.x - o.y) * inv.y;
-    float z0 = (na.z - o.z) * inv.z, z1 = (nb.y - o.z) * inv.z;
-    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
-    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-    start = __builtin_fmaxf(start, tn);
-    start_out = start;
-    return tf > start && !(best < start);
-}
-
 TRT_DEV bool finite_f(float v) { return __builtin_fabsf(v) < __builtin_inff(); }
 
 // ------------------------------------------------------------------------------------------------

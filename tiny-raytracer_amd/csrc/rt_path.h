@@ -377,34 +377,58 @@ TRT_DEV bool leaf_hit_t(const SceneAcc<MODE>& sc, const Ray& ray, uint32_t leaf,
     return sphere_test(sc.sphere(idx), ray, kTMin, limit, t_out);      // Sphere::hit, sphere.rs:29-54
 }
 
-// EXPERIMENTAL (opt-in, TRT_ORDERED_WALK=1): near-first walk for scenes in global memory.
-// Known gap: a true winner that is itself unsafe (own t below its box entry) can be culled by a slightly farther
-// candidate before it is ever tested, so the safe-winner check never sees it: 48 of 2.6e7 rays differ on the 100 k
-// touching-spheres scene.  The fixed-order walks stay the default.  `nodes16` is this ray's octant array of a
-// free-order SAH tree: pre-order with the child that is nearer along the split axis first, 16-byte nodes as in
-// walk_compact.  Visiting order no longer matters for the result, because the result is defined without it:
+// OPT-IN (TRT_ORDERED_WALK=1): near-first walk for sphere-only scenes in global memory.
+// `nodes16` is this ray's octant array of a free-order SAH tree: pre-order with the child that is nearer along the split
+// axis first, 16-byte nodes as in walk_compact.  Visiting order does not matter for the result, because the result is
+// defined without it:
 //   the hit is the primitive with the smallest own hit distance, ties going to the smaller leaf sequence number,
-// which IS the reference's answer whenever that winner's distance is not below the entry of its own exact leaf box
-// (tests/native/ordered_theorem_check.c), "primitive" meaning one the reference can reach at all: its exact leaf box
-// must have t_far > start (slab_leaf_candidate).  So: boxes are culled only when they start strictly beyond the best
-// distance so far (a tie may still be won on sequence), a candidate replaces the best on t < best or on equal t with a
-// smaller sequence number, and the function returns false for the (rounding-level rare) ray whose winner is unsafe -
-// the caller then re-traces it with the fixed-order walk.
+// which IS the reference's answer whenever that winner is "safe" - its distance not below the entry of its own exact
+// leaf box (tests/native/ordered_theorem_check.c) - "primitive" meaning one the reference can reach at all (exact
+// leaf box with t_far > start).  The walk keeps that arg-min over what it visits:
+//   * a box is culled against the best SAFE candidate's distance t_cull, and only if its entry lies beyond
+//     t_cull + kOrderedGap * D, D = the largest |box plane - origin| of the box: everything culled should then have an
+//     own distance strictly above t_cull and so cannot be the arg-min, whatever its place in the reference's order;
+//   * a candidate replaces the best on smaller t, or equal t and smaller sequence number;
+//   * the function returns false for the (rounding-level rare) ray whose winner is unsafe; the caller re-traces it
+//     with the fixed-order walk.
+// NOT PROVEN, hence opt-in: the band must exceed how far a primitive's computed distance can undercut its box entry.
+// For spheres that is up to 3.3e-3 D in 2.4e7 tangent-aimed test rays, but it has no uniform bound - a false hit
+// reported just outside a box face is followed by a box entry 1/|d_axis| later, unbounded for rays nearly parallel to
+// the face.  Measured: bit-identical to the fixed-order walk on every scene tried, including 8e8 rays of the 100 k
+// touching-spheres scene (without the band, 48 of 2.6e7 rays differed).  Quads (grazing plane distances) are excluded.
+constexpr float kOrderedGap = 5.0e-3f;
+
 template <int MODE, bool STATS>
 TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
                           const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
     const uint32_t n = sc.L.n_ordered_nodes;
     uint32_t seq_best = 0xFFFFFFFFu;
-    float start_best = 0.0f;
+    bool safe_best = true;
+    float t_cull = __builtin_inff();                                                        // best safe candidate
     tr.i = 0u;
+    // does the box [lo, hi] pass: the ray crosses it (t_far >= start; `strict`: > as the reference needs for a leaf) and
+    // its entry is not beyond t_cull by more than the worst unsafety of anything inside it
+    auto box_passes = [&](V3 lo, V3 hi, bool strict, float& start_out) {
+        const V3 dl = lo - ray.o, dh = hi - ray.o;
+        const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(dl.x), __builtin_fabsf(dh.x)),
+                                                           __builtin_fmaxf(__builtin_fabsf(dl.y), __builtin_fabsf(dh.y))),
+                                           __builtin_fmaxf(__builtin_fabsf(dl.z), __builtin_fabsf(dh.z)));
+        const float x0 = dl.x * tr.inv.x, x1 = dh.x * tr.inv.x, y0 = dl.y * tr.inv.y, y1 = dh.y * tr.inv.y, z0 = dl.z * tr.inv.z, z1 = dh.z * tr.inv.z;
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+        const float start = __builtin_fmaxf(kTMin, tn);
+        start_out = start;
+        const bool crosses = strict ? tf > start : !(tf < start);
+        return crosses && !(start > t_cull + kOrderedGap * dmax);
+    };
     for (;;) {
         uint32_t cnt = 0;
         while (tr.i < n && cnt < slots) {
             const uint4 q = nodes16[tr.i];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
             const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
-            const bool pass = slab_ge6(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), ray.o, tr.inv,
-                                       kTMin, tr.t_best);
+            float start;
+            const bool pass = box_passes(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), false, start);
             const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
             if (pass && is_leaf) {
                 stk[64u * cnt] = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), 0.0f);
@@ -418,23 +442,25 @@ TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
             const float4 na = leaf_list[2u * seq], nb = leaf_list[2u * seq + 1u];
             if constexpr (STATS) ctr.node++;
             float start;
-            if (slab_leaf_candidate(na, nb, ray.o, tr.inv, kTMin, tr.t_best, start)) {     // exact leaf box: reachable, and not beyond the best
+            if (box_passes(v3(na.x, na.y, na.z), v3(na.w, nb.x, nb.y), true, start)) {     // exact leaf box: reachable, and not safely beyond
                 if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
                 // own hit distance up to and including the best so far (next float above it as the exclusive limit)
                 const float limit = tr.t_best < __builtin_inff() ? __uint_as_float(__float_as_uint(tr.t_best) + 1u) : tr.t_best;
                 float t;
                 if (leaf_hit_t<MODE, STATS>(sc, ray, __float_as_uint(nb.w), limit, t, ctr)) {
+                    const bool safe = t >= start;
+                    if (safe) t_cull = __builtin_fminf(t_cull, t);
                     if (t < tr.t_best || seq < seq_best) {                               // t <= t_best here; equal t: the earlier leaf wins
                         tr.t_best = t;
                         tr.prim_best = __float_as_uint(nb.w);
                         seq_best = seq;
-                        start_best = start;
+                        safe_best = safe;
                     }
                 }
             }
         }
     }
-    return tr.prim_best == PRIM_NONE || tr.t_best >= start_best;                          // is the winner safe?
+    return safe_best;
 }
 
 constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)

@@ -427,10 +427,11 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     }
     L.off_ordered = 0u;
     L.n_ordered_nodes = 0u;
-    // near-first walk (rt_path.h walk_ordered): EXPERIMENTAL, opt-in.  Not bit-exact yet: ~2e-6 of the rays of the
-    // 100 k-sphere scene differ (an unsafe true winner can be culled before it is ever tested: DESIGN.md section 10)
+    // near-first walk (rt_path.h walk_ordered): OPT-IN (TRT_ORDERED_WALK=1), sphere-only scenes walked from global memory.
+    // Bit-identical to the fixed-order walk on every scene measured, but its culling band is not proven (DESIGN.md
+    // section 10), so it is not what ships by default.
     bool want_ordered = false;
-    if (const char* e = getenv("TRT_ORDERED_WALK")) want_ordered = want_compact && atoi(e) != 0;
+    if (const char* e = getenv("TRT_ORDERED_WALK")) want_ordered = want_compact && nq == 0u && atoi(e) != 0;
     if (want_ordered) {
         L.n_ordered_nodes = 2u * L.n_leaves - 1u;
         L.off_ordered = L.blob_bytes / 16u;
