@@ -386,17 +386,20 @@ TRT_DEV bool leaf_hit_t(const SceneAcc<MODE>& sc, const Ray& ray, uint32_t leaf,
 // leaf box (tests/native/ordered_theorem_check.c) - "primitive" meaning one the reference can reach at all (exact
 // leaf box with t_far > start).  The walk keeps that arg-min over what it visits:
 //   * a box is culled against the best SAFE candidate's distance t_cull, and only if its entry lies beyond
-//     t_cull + kOrderedGap * D, D = the largest |box plane - origin| of the box: everything culled should then have an
-//     own distance strictly above t_cull and so cannot be the arg-min, whatever its place in the reference's order;
+//     t_cull + eps * max|1/d_axis|, eps = min(kOrderedGap * D, kOrderedGapR * D^2 / r_min), D = the largest
+//     |box plane - origin| of the box.  A sphere's reported hit point satisfies the sphere's equation up to the
+//     backward error of the float evaluation, | |P - c|^2 - r^2 | <= ~24u (|o - c| + r)^2, so it lies within eps of the
+//     ball, hence of every box above it, and such a box is entered at most eps / |d_axis| later: everything culled has
+//     an own distance strictly above t_cull and cannot be the arg-min, whatever its place in the reference's order;
 //   * a candidate replaces the best on smaller t, or equal t and smaller sequence number;
 //   * the function returns false for the (rounding-level rare) ray whose winner is unsafe; the caller re-traces it
 //     with the fixed-order walk.
-// NOT PROVEN, hence opt-in: the band must exceed how far a primitive's computed distance can undercut its box entry.
-// For spheres that is up to 3.3e-3 D in 2.4e7 tangent-aimed test rays, but it has no uniform bound - a false hit
-// reported just outside a box face is followed by a box entry 1/|d_axis| later, unbounded for rays nearly parallel to
-// the face.  Measured: bit-identical to the fixed-order walk on every scene tried, including 8e8 rays of the 100 k
-// touching-spheres scene (without the band, 48 of 2.6e7 rays differed).  Quads (grazing plane distances) are excluded.
-constexpr float kOrderedGap = 5.0e-3f;
+// Opt-in this round: the backward-error constant is a hand derivation (measured margin: hit points at most 7e-5 D
+// outside their box in 2.4e7 tangent-aimed rays, against 5.5e-3 D allowed).  Measured: bit-identical to the fixed-order
+// walk on every scene tried, including 8e8 rays of the 100 k touching-spheres scene (with a plain strict cull, 48 of
+// 2.6e7 rays differed).  Quads (grazing plane distances) have no such bound: scenes with quads keep walk_compact.
+constexpr float kOrderedGap = 5.5e-3f;        // see walk_ordered: worst distance of a false sphere hit from its box, per unit of D
+constexpr float kOrderedGapR = 9.0e-6f;       // the same per unit of D^2 / r (spheres of radius >= r)
 
 template <int MODE, bool STATS>
 TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
@@ -405,6 +408,11 @@ TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
     uint32_t seq_best = 0xFFFFFFFFu;
     bool safe_best = true;
     float t_cull = __builtin_inff();                                                        // best safe candidate
+    // a point up to eps outside a box face is followed by the box entry at most eps / |d_axis| later; eps is the smaller of
+    // kOrderedGap * D (any radius) and kOrderedGapR * D^2 / r_min (the residual bound divided by 2r)
+    const float max_inv = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(tr.inv.x), __builtin_fabsf(tr.inv.y)), __builtin_fabsf(tr.inv.z));
+    const float band_per_d = kOrderedGap * max_inv;
+    const float band_per_d2 = sc.L.inv_r_min > 0.0f ? kOrderedGapR * sc.L.inv_r_min * max_inv : __builtin_inff();
     tr.i = 0u;
     // does the box [lo, hi] pass: the ray crosses it (t_far >= start; `strict`: > as the reference needs for a leaf) and
     // its entry is not beyond t_cull by more than the worst unsafety of anything inside it
@@ -419,7 +427,7 @@ TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
         const float start = __builtin_fmaxf(kTMin, tn);
         start_out = start;
         const bool crosses = strict ? tf > start : !(tf < start);
-        return crosses && !(start > t_cull + kOrderedGap * dmax);
+        return crosses && !(start > t_cull + __builtin_fminf(band_per_d * dmax, band_per_d2 * dmax * dmax));
     };
     for (;;) {
         uint32_t cnt = 0;

@@ -428,11 +428,15 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     L.off_ordered = 0u;
     L.n_ordered_nodes = 0u;
     // near-first walk (rt_path.h walk_ordered): OPT-IN (TRT_ORDERED_WALK=1), sphere-only scenes walked from global memory.
-    // Bit-identical to the fixed-order walk on every scene measured, but its culling band is not proven (DESIGN.md
-    // section 10), so it is not what ships by default.
+    // Bit-identical to the fixed-order walk on every scene measured; opt-in until its culling band's derivation has been
+    // reviewed.
     bool want_ordered = false;
     if (const char* e = getenv("TRT_ORDERED_WALK")) want_ordered = want_compact && nq == 0u && atoi(e) != 0;
+    L.inv_r_min = 0.0f;
     if (want_ordered) {
+        float r_min = INFINITY;
+        for (const F4& sp : spheres) { const float r = fabsf(sp.w); if (r < r_min) r_min = r; }
+        if (r_min > 0.0f && r_min < INFINITY) L.inv_r_min = 1.0f / r_min;
         L.n_ordered_nodes = 2u * L.n_leaves - 1u;
         L.off_ordered = L.blob_bytes / 16u;
         L.blob_bytes += 8u * 16u * L.n_ordered_nodes;
