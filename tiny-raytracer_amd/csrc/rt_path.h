@@ -386,10 +386,10 @@ TRT_DEV bool leaf_hit_t(const SceneAcc<MODE>& sc, const Ray& ray, uint32_t leaf,
 // leaf box (tests/native/ordered_theorem_check.c) - "primitive" meaning one the reference can reach at all (exact
 // leaf box with t_far > start).  The walk keeps that arg-min over what it visits:
 //   * a box is culled against the best SAFE candidate's distance t_cull, and only if its entry lies beyond
-//     t_cull + eps * max|1/d_axis|, eps = min(kOrderedGap * D, kOrderedGapR * D^2 / r_min), D = the largest
-//     |box plane - origin| of the box.  A sphere's reported hit point satisfies the sphere's equation up to the
+//     t_cull + eps / |d_j|, j = the axis of the box's entry plane, eps = min(kOrderedGap * D, kOrderedGapR * D^2 / r_min),
+//     D = the largest |box plane - origin| of the box.  A sphere's reported hit point satisfies the sphere's equation up to the
 //     backward error of the float evaluation, | |P - c|^2 - r^2 | <= ~24u (|o - c| + r)^2, so it lies within eps of the
-//     ball, hence of every box above it, and such a box is entered at most eps / |d_axis| later: everything culled has
+//     ball, hence of every box above it, and such a box is entered at most eps / |d_j| later: everything culled has
 //     an own distance strictly above t_cull and cannot be the arg-min, whatever its place in the reference's order;
 //   * a candidate replaces the best on smaller t, or equal t and smaller sequence number;
 //   * the function returns false for the (rounding-level rare) ray whose winner is unsafe; the caller re-traces it
@@ -408,11 +408,11 @@ TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
     uint32_t seq_best = 0xFFFFFFFFu;
     bool safe_best = true;
     float t_cull = __builtin_inff();                                                        // best safe candidate
-    // a point up to eps outside a box face is followed by the box entry at most eps / |d_axis| later; eps is the smaller of
-    // kOrderedGap * D (any radius) and kOrderedGapR * D^2 / r_min (the residual bound divided by 2r)
-    const float max_inv = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(tr.inv.x), __builtin_fabsf(tr.inv.y)), __builtin_fabsf(tr.inv.z));
-    const float band_per_d = kOrderedGap * max_inv;
-    const float band_per_d2 = sc.L.inv_r_min > 0.0f ? kOrderedGapR * sc.L.inv_r_min * max_inv : __builtin_inff();
+    // a point up to eps outside a box is followed by the box entry at most eps / |d_j| later, j = the axis whose near
+    // plane is the entry (the other slabs were entered before); eps is the smaller of kOrderedGap * D (any radius)
+    // and kOrderedGapR * D^2 / r_min (the residual bound divided by 2r)
+    const V3 ainv = v3(__builtin_fabsf(tr.inv.x), __builtin_fabsf(tr.inv.y), __builtin_fabsf(tr.inv.z));
+    const float gap_r = sc.L.inv_r_min > 0.0f ? kOrderedGapR * sc.L.inv_r_min : __builtin_inff();
     tr.i = 0u;
     // does the box [lo, hi] pass: the ray crosses it (t_far >= start; `strict`: > as the reference needs for a leaf) and
     // its entry is not beyond t_cull by more than the worst unsafety of anything inside it
@@ -422,12 +422,15 @@ TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
                                                            __builtin_fmaxf(__builtin_fabsf(dl.y), __builtin_fabsf(dh.y))),
                                            __builtin_fmaxf(__builtin_fabsf(dl.z), __builtin_fabsf(dh.z)));
         const float x0 = dl.x * tr.inv.x, x1 = dh.x * tr.inv.x, y0 = dl.y * tr.inv.y, y1 = dh.y * tr.inv.y, z0 = dl.z * tr.inv.z, z1 = dh.z * tr.inv.z;
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+        const float nx = __builtin_fminf(x0, x1), ny = __builtin_fminf(y0, y1), nz = __builtin_fminf(z0, z1);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
         const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
         const float start = __builtin_fmaxf(kTMin, tn);
         start_out = start;
         const bool crosses = strict ? tf > start : !(tf < start);
-        return crosses && !(start > t_cull + __builtin_fminf(band_per_d * dmax, band_per_d2 * dmax * dmax));
+        const float inv_entry = tn == nx ? ainv.x : (tn == ny ? ainv.y : ainv.z);
+        const float eps = __builtin_fminf(kOrderedGap * dmax, gap_r * dmax * dmax);
+        return crosses && !(start > t_cull + eps * inv_entry);
     };
     for (;;) {
         uint32_t cnt = 0;
