@@ -264,3 +264,18 @@ def test_f16_outward_rounding_handles_the_edges(trt, monkeypatch):
     with np.errstate(over="ignore"):
         assert (np.nextafter(lo16, np.float16(np.inf)).astype(np.float32)[fin] > box[:, :3][fin]).all()
         assert (np.nextafter(hi16, np.float16(-np.inf)).astype(np.float32)[fin] < box[:, 3:][fin]).all()
+
+
+def test_header_is_valid_c_and_the_c_example_fails_loudly_without_gpu(trt, tmp_path):
+    """include/tinyrt.h is a C header: examples/minimal.c builds with gcc -std=c11 -pedantic against it; without a GPU
+    the example exits 1 with the library's NO_DEVICE message."""
+    import subprocess
+    exe = str(tmp_path / "minimal")
+    libdir = os.path.join(ROOT, "tiny-raytracer_amd")
+    subprocess.run(["gcc", "-std=c11", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "minimal.c"), "-L" + libdir, "-ltinyrt", "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, cwd=str(tmp_path))
+    if trt.lib.trt_device_count() > 0:
+        assert r.returncode == 0 and "rays in" in r.stdout and os.path.exists(tmp_path / "minimal.ppm")
+    else:
+        assert r.returncode == 1 and "no HIP device visible" in r.stderr
