@@ -51,7 +51,7 @@ static float slab_start(const orc_aabb *b, const orc_ray *ray, float *t_far, flo
     return tn > 0.001f ? tn : 0.001f;
 }
 
-static double g_worst_gap_rel = 0.0, g_worst_gap_d = 0.0, g_worst_out_d = 0.0;     /* worst (start - t) / (|o-c| + r) and / D over all sphere hits */
+static double g_worst_gap_rel = 0.0, g_worst_gap_d = 0.0, g_worst_out_d = 0.0, g_worst_residual = 0.0;     /* worst (start - t) / (|o-c| + r) and / D over all sphere hits */
 
 static int check_scene(const char *name, const prim_t *prims, int n, float extent, long n_rays, int on_surface) {
     orc_world *w = orc_world_new();
@@ -120,6 +120,14 @@ static int check_scene(const char *name, const prim_t *prims, int n, float exten
             orc_hit_record h;
             int ok = p->kind == 0 ? orc_sphere_hit(p->a, p->r, &ray, 0.001f, INFINITY, &h) : orc_quad_hit(p->a, p->b, p->c, &ray, 0.001f, INFINITY, &h);
             if (!ok) continue;
+            if (p->kind == 0) {                       /* backward error of Sphere::hit: | |P - c|^2 - r^2 | / (|o - c| + r)^2 at the reported t */
+                const double px = (double)ray.origin.x + (double)h.t * ray.direction.x - p->a.x, py = (double)ray.origin.y + (double)h.t * ray.direction.y - p->a.y,
+                             pz = (double)ray.origin.z + (double)h.t * ray.direction.z - p->a.z;
+                const double ox = (double)ray.origin.x - p->a.x, oy = (double)ray.origin.y - p->a.y, oz = (double)ray.origin.z - p->a.z;
+                const double scale = sqrt(ox * ox + oy * oy + oz * oz) + p->r;
+                const double res = fabs(px * px + py * py + pz * pz - (double)p->r * p->r) / (scale * scale);
+                if (res > g_worst_residual) g_worst_residual = res;
+            }
             if (p->kind == 0 && d.x != 0.0f && d.y != 0.0f && d.z != 0.0f) {           /* how far can a sphere's t undercut its box entry? */
                 float tfar, dmax;
                 const float st = slab_start(&lbox[k], &ray, &tfar, &dmax);
@@ -223,6 +231,7 @@ int main(int argc, char **argv) {
      * near-first walk culls beyond t_cull + 5.5e-3 D max|1/d_axis| (rt_path.h kOrderedGap). */
     printf("worst sphere unsafety: (start - t) / (|o-c| + r) = %.3e, / D = %.3e; hit point outside its box by %.3e D (walk_ordered allows 5.5e-3 D)\n",
            g_worst_gap_rel, g_worst_gap_d, g_worst_out_d);
-    if (g_worst_out_d > 5.5e-3) fail = 1;
+    printf("worst backward error of Sphere::hit: | |P-c|^2 - r^2 | / (|o-c| + r)^2 = %.3e (derived bound 24 u = 1.43e-6)\n", g_worst_residual);
+    if (g_worst_out_d > 5.5e-3 || g_worst_residual > 1.43e-6) fail = 1;
     return fail;
 }

@@ -24,5 +24,7 @@ def test_argmin_with_walk_order_ties_is_the_reference_result_when_the_winner_is_
         assert int(unsafe) <= 0.02 * int(hits), name               # the fallback must stay rare
     m = re.search(r"hit point outside its box by ([0-9.e+-]+) D", r.stdout)
     assert m and float(m.group(1)) <= 5.5e-3                                          # the spatial bound behind walk_ordered's culling band
+    m = re.search(r"worst backward error of Sphere::hit: .* = ([0-9.e+-]+) ", r.stdout)
+    assert m and float(m.group(1)) <= 1.43e-6                                         # the derived constant 24 u of DESIGN.md section 10
     by = {row[0]: row for row in rows}
     assert int(by["cornell"][4]) > 0 and int(by["coincident"][4]) > 0          # exact ties did occur and were resolved by walk order
