@@ -130,6 +130,125 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     flush_counters<STATS>(counters, n_samples, n_rays, ctr);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Same kernel with the primary rays of a whole wave generated at once.  In the kernel above a lane keeps one primary
+// ray in stock (9 VGPRs) and the generation code runs whenever some lane is out of stock: 0.45 times per bounce
+// round with 30 % of the lanes busy.  Here an empty per-wave pool in LDS (64 entries x 36 bytes behind the leaf
+// stack) is refilled by ALL 64 lanes - the next 64 items of the batch, off-image ones dropped, entries compacted by
+// ballot rank - and lanes whose path ended take entries by rank: generation runs once per ~7 rounds with every lane
+// busy, and the stock registers are gone.  Which lane traces which sample changes; every sample's radiance does not
+// (RNG keyed by pixel and sample, radiance stored per sample, folded in order).  Used where the pool costs no resident
+// workgroup (small LDS scene copies).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPoolDwords = 9u;         // origin, direction, rng state, radiance slot
+
+template <int MODE, bool STATS, int MINW = 1, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd, CameraDev cam, RenderArgs ra,
+                                                                           float* __restrict__ colors,
+                                                                           uint32_t* __restrict__ batch_counter,
+                                                                           unsigned long long* __restrict__ counters,
+                                                                           uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp,
+                                                                           const float4* __restrict__ leaf_list,
+                                                                           const uint4* __restrict__ nodes16,
+                                                                           const uint4* __restrict__ ordered16) {
+    stage_scene_to_lds<MODE>(scd);
+    const SceneAcc<MODE> sc{scd.blob, scd.L};
+    const uint32_t lane = threadIdx.x & 63u;
+    const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
+    const uint32_t n_spp = ra.sample_end - ra.sample_begin;
+    const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
+    char* const lds_tail = reinterpret_cast<char*>(g_lds) + ((sc.lds_bytes() + 15u) & ~15u);
+    float2* const leaf_stack = reinterpret_cast<float2*>(lds_tail) + (threadIdx.x >> 6) * (64u * ra.leaf_slots) + lane;
+    // the pool: field f of entry e at pool[f * 64 + e]
+    uint32_t* const pool = reinterpret_cast<uint32_t*>(lds_tail + (size_t)THREADS * ra.leaf_slots * sizeof(float2)) + (threadIdx.x >> 6) * (64u * kPoolDwords);
+
+    uint32_t tile_x0 = 0, tile_row0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // wave-uniform work cursor
+    uint32_t pool_head = 0, pool_count = 0;                                            // wave-uniform
+    bool exhausted = false;
+
+    Path p;
+    p.remain = 0u;
+    bool has_path = false;
+    uint32_t out_idx = 0;
+    uint32_t n_samples = 0, n_rays = 0;
+    Counters<STATS> ctr;
+
+    for (;;) {
+        // ---- lanes without a path take pool entries; an empty pool is refilled by the whole wave ----
+        for (;;) {
+            const uint64_t need = __builtin_amdgcn_ballot_w64(!has_path);
+            if (need == 0ull) break;
+            if (pool_count == 0u) {
+                if (exhausted) break;
+                if (cursor >= items_per_batch) {
+                    uint32_t b = 0;
+                    if (lane == 0u) b = atomicAdd(batch_counter, 1u);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    if (b >= n_batches) { exhausted = true; break; }
+                    const uint32_t tile = b % n_tiles;                                    // consecutive batches: neighbouring tiles, same samples
+                    ds0 = (b / n_tiles) * batch_spp;
+                    tile_x0 = (tile % tiles_x) * 8u;
+                    tile_row0 = (tile / tiles_x) * 8u;
+                    items_per_batch = 64u * (n_spp - ds0 < batch_spp ? n_spp - ds0 : batch_spp);
+                    cursor = 0;
+                }
+                // the next 64 items: one 8x8 tile at one sample index
+                const uint32_t item = cursor + lane;
+                cursor += 64u;
+                const uint32_t ds = ds0 + (item >> 6);
+                const uint32_t x = tile_x0 + (lane & 7u), row = tile_row0 + (lane >> 3);
+                const bool valid = x < cam.width && row < ra.rows_local;                  // off-image items of an edge tile are dropped
+                const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+                if (valid) {
+                    if constexpr (STATS) { if (first_active_lane()) ctr.w_gen++; }
+                    const uint32_t y = image_row(ra, row);
+                    Rng rng = rng_seed(ra.seed_key, y * cam.width + x, ra.sample_begin + ds);        // cpu.rs:42-45
+                    const Ray ray = primary_ray(cam, x, y, rng);
+                    const uint32_t e = st_rank(vmask);
+                    pool[0u * 64u + e] = __float_as_uint(ray.o.x); pool[1u * 64u + e] = __float_as_uint(ray.o.y); pool[2u * 64u + e] = __float_as_uint(ray.o.z);
+                    pool[3u * 64u + e] = __float_as_uint(ray.d.x); pool[4u * 64u + e] = __float_as_uint(ray.d.y); pool[5u * 64u + e] = __float_as_uint(ray.d.z);
+                    pool[6u * 64u + e] = rng.s0; pool[7u * 64u + e] = rng.s1;
+                    pool[8u * 64u + e] = ds * (uint32_t)n_pixels + row * cam.width + x;
+                }
+                pool_head = 0u;
+                pool_count = (uint32_t)__builtin_popcountll(vmask);
+                if (pool_count == 0u) continue;                                           // a tile row entirely off the image
+            }
+            const uint32_t rank = st_rank(need);
+            if (!has_path && rank < pool_count) {
+                const uint32_t e = pool_head + rank;
+                p.ray.o = v3(__uint_as_float(pool[0u * 64u + e]), __uint_as_float(pool[1u * 64u + e]), __uint_as_float(pool[2u * 64u + e]));
+                p.ray.d = v3(__uint_as_float(pool[3u * 64u + e]), __uint_as_float(pool[4u * 64u + e]), __uint_as_float(pool[5u * 64u + e]));
+                p.rng.s0 = pool[6u * 64u + e]; p.rng.s1 = pool[7u * 64u + e];
+                out_idx = pool[8u * 64u + e];
+                p.color = v3(0.0f, 0.0f, 0.0f);
+                p.atten = v3(1.0f, 1.0f, 1.0f);
+                p.remain = ra.max_bounces;
+                has_path = true;
+                n_samples++;
+            }
+            const uint32_t wanted = (uint32_t)__builtin_popcountll(need);
+            const uint32_t taken = wanted < pool_count ? wanted : pool_count;
+            pool_head += taken;
+            pool_count -= taken;
+        }
+        if (__builtin_amdgcn_ballot_w64(has_path) == 0ull) break;                         // nothing left to trace: the batches are used up
+        if (has_path) {
+            if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
+            n_rays++;
+            float t;
+            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
+            if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
+                float* c = colors + 3ull * out_idx;
+                c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                has_path = false;
+            }
+        }
+    }
+    flush_counters<STATS>(counters, n_samples, n_rays, ctr);
+}
+
 // pixels[idx] += color * (1/spp), samples in order (imager.rs:35,50)
 __global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restrict__ colors, float* __restrict__ accum,
                                                           unsigned long long n_pixels, uint32_t n_spp, float inv_spp,
@@ -206,7 +325,6 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         const uint32_t fit_stack = (uint32_t)(160u * 1024u / with_stack);
         lds_stack = (fit_stack < wg_per_cu ? fit_stack : wg_per_cu) >= (fit_plain < wg_per_cu ? fit_plain : wg_per_cu);
     }
-    const size_t lds_bytes = lds_stack ? with_stack : scene_bytes;
     // few primitives: lock-step leaf list (rt_path.h walk_flat); needs the LDS stack for its postponed leaves
     // scenes read from global memory: 16-byte culling nodes (rt_path.h walk_compact); it tests postponed leaves against
     // their exact boxes in the leaf list
@@ -216,6 +334,13 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     // ... walked near-first through a free-order tree (rt_path.h walk_ordered); the compact fixed-order tree re-traces
     // the rays whose winner is not safe
     const uint4* ordered16 = (compact && sc.L.off_ordered != 0u) ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_ordered) : nullptr;
+    // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack, 256-lane workgroups of a scene copied to
+    // LDS at 6 waves per SIMD, and must not cost a resident workgroup either
+    const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
+    bool pool = lds_stack && mode == MODE_LDS && threads == 256 && w == 6 && !ra_all.ref_tree;
+    if (const char* env = getenv("TRT_RAY_POOL")) pool = pool && atoi(env) != 0;
+    if (pool) pool = (uint32_t)(160u * 1024u / (with_stack + pool_bytes)) >= wg_per_cu;
+    const size_t lds_bytes = lds_stack ? with_stack + (pool ? pool_bytes : 0u) : scene_bytes;
     if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
     const uint32_t resident = (uint32_t)cus * wg_per_cu;
     const uint32_t waves_per_wg = (uint32_t)threads / 64u;
@@ -249,6 +374,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                     if (w >= 6) e = launch_pick<MODE_LDS, 6, 512>(stats, go);
                     else e = launch_pick<MODE_LDS, 5, 512>(stats, go);
                 } else if (w >= 7) e = launch_pick<MODE_LDS, 7, 256>(stats, go);
+                else if (w == 6 && pool) e = stats ? go(stream_pool_kernel<MODE_LDS, true, 6, 256>) : go(stream_pool_kernel<MODE_LDS, false, 6, 256>);
                 else if (w == 6) e = launch_pick<MODE_LDS, 6, 256>(stats, go);
                 else e = launch_pick<MODE_LDS, 5, 256>(stats, go);
                 break;
