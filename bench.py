@@ -13,6 +13,7 @@ one RCCL gather of the accumulators to rank 0 closes the frame inside the timed 
 device (one ray = one closest-hit query = one `world.hit` call, reference cpu.rs:48).
 """
 import argparse
+import ctypes as C
 import importlib
 import json
 import os
@@ -126,7 +127,7 @@ def main():
         args.backend = "streamed"
     backend = {"wavefront": trt.BACKEND_WAVEFRONT, "streamed": trt.BACKEND_STREAMED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
     renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1, backend=backend)
-    kernel_name = {"wavefront": "trt::wavefront_kernel", "streamed": "trt::stream_sample_kernel"}.get(args.backend, "trt::megakernel")
+    kernel_name = trt.lib.trt_dominant_kernel(scene._h, C.byref(cam.pod), C.byref(renderer.params())).decode()      # what a kernel trace of a step shows
 
     lay = tiles.band_layout(H, world_size, rank)
     band = dict(band_rows=lay["band_rows"], band_stride=lay["band_stride"], band_offset=lay["band_offset"],

@@ -166,6 +166,8 @@ extern "C" {
     pub fn trt_tonemap_u8_device(d_accum: *const f32, npixels: u32, gamma: f32, d_rgb: *mut u8, stream: *mut c_void) -> c_int;
     pub fn trt_streamed_chunk_spp(width: u32, rows: u32) -> u32;
 
+    pub fn trt_dominant_kernel(s: *const trt_scene, cam: *const trt_camera, p: *const trt_render_params) -> *const c_char;
+
     pub fn trt_last_error() -> *const c_char;
     pub fn trt_device_count() -> c_int;
     pub fn trt_set_device(ordinal: c_int) -> c_int;

@@ -183,6 +183,10 @@ int trt_tonemap_u8_device(const float *d_accum, uint32_t npixels, float gamma, u
  * ranges into such chunks; one chunk = one `trt::stream_sample_kernel` launch + one fold launch). */
 uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows);
 
+/* Name of the GPU kernel that dominates a render of this scene with these settings ("trt::stream_pool_kernel", ...): what
+ * a kernel trace of the call shows, for profiles and benchmark records.  "" on invalid arguments. */
+const char *trt_dominant_kernel(const trt_scene *s, const trt_camera *cam, const trt_render_params *p);
+
 /* ---- library ---- */
 const char *trt_last_error(void);
 int trt_device_count(void);               /* gfx950 devices visible; 0 without a GPU (never an error) */

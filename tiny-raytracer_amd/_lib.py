@@ -100,6 +100,7 @@ SIGNATURES = {
     "trt_streamed_chunk_spp": (C.c_uint32, [C.c_uint32, C.c_uint32]),
     "trt_tonemap_u8": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]),
     "trt_tonemap_u8_device": (C.c_int, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p]),
+    "trt_dominant_kernel": (C.c_char_p, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams)]),
     "trt_last_error": (C.c_char_p, []),
     "trt_device_count": (C.c_int, []),
     "trt_set_device": (C.c_int, [C.c_int]),

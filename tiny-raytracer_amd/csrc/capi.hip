@@ -440,6 +440,17 @@ int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_s
 
 uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows) { return streamed_chunk_spp(width, rows); }
 
+// Name of the kernel that dominates a render with these settings (what a profile of it shows).
+const char* trt_dominant_kernel(const trt_scene* s, const trt_camera* cam, const trt_render_params* p) {
+    if (!s || !cam || !p) return "";
+    RenderArgs ra;
+    uint32_t rows = 0;
+    if (to_render_args(cam, p, ra, rows) != TRT_OK) return "";
+    if (p->backend == TRT_BACKEND_WAVEFRONT) return "trt::wavefront_kernel";
+    if (p->backend == TRT_BACKEND_MEGAKERNEL) return "trt::megakernel";
+    return streamed_kernel_name(s->host.layout, ra);
+}
+
 // ---- Imager finalisation ----
 int trt_tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* rgb) {
     if (npixels && (!accum || !rgb)) return fail(TRT_ERR_INVALID_ARG, "null argument");

@@ -69,6 +69,7 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
 // Streamed backend (streamed.hip): samples are work items; radiances go to an HBM buffer and are folded in order.
 uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows);   // samples per pixel per sample/fold launch pair (bounds the radiance buffer)
 size_t streamed_workspace_bytes(uint32_t width, uint32_t rows);
+const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra);
 hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
                            unsigned long long* d_counters, bool stats, hipStream_t stream);
 

@@ -17,7 +17,9 @@
 //    frame is bit-identical to the megakernel's and the oracle's whatever lane computed which sample.
 //
 // Cost: 12 B written + 12 B read per sample (a sample is ~7 rays, ~4.6 KB algorithmic), i.e. <1 % extra traffic, and
-// two launches per chunk of samples (sized to a ~4 GB radiance buffer) instead of one.  The primary-ray stock of kernels.hip is kept (items are taken ahead).
+// two launches per chunk of samples (sized to a ~4 GB radiance buffer) instead of one.  stream_sample_kernel keeps the
+// primary-ray stock of kernels.hip (items are taken ahead); stream_pool_kernel, used for small LDS scenes, generates the
+// primary rays of a whole wave at once into an LDS pool.
 #include <stdlib.h>
 
 #include "kernels.h"
@@ -284,6 +286,66 @@ size_t streamed_workspace_bytes(uint32_t width, uint32_t rows) {
     return (size_t)width * rows * streamed_chunk_spp(width, rows) * 3 * sizeof(float) + 256;      // radiance buffer + batch counter
 }
 
+// How a scene is launched: workgroup shape, waves per SIMD, where the postponed leaves live, which walk, which kernel.
+struct StreamPlan {
+    int mode, threads, w;
+    uint32_t wg_per_cu, slots;
+    bool lds_stack, flat, compact, ordered, pool;
+    size_t lds_bytes;
+};
+
+static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) {
+    StreamPlan pl{};
+    const size_t scene_bytes = scene_lds_bytes(L);
+    const int mode = scene_mode(L);
+    // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies, 512-lane workgroups sharing a big
+    // LDS copy between 8 waves, 8 waves per SIMD for scenes read from global memory
+    const int threads = (mode == MODE_LDS && L.hot_bytes > 20u * 1024u) ? 512 : 256;
+    // LDS scenes: 6 waves per SIMD (80 VGPRs, 21 spilled) beat 7 (72 VGPRs, 38 spilled) by 3 % and 5 (no spills) by 2 % on
+    // Cornell.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box step once the
+    // compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6, 2.29 at 8)
+    int w = mode == MODE_LDS ? 6 : 8;
+    if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
+    if (w < 5) w = 5;
+    if (threads == 512 && w > 6) w = 6;
+    uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
+    // slots of the LDS stack: 4 for tree walks; 6 for the lock-step leaf list, whose t_best stays stale for a whole walk
+    // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12)
+    const bool flat = L.flat_walk && !ra_all.ref_tree;
+    const uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 6u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
+    const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
+    const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
+    // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
+    // resident workgroup (random-spheres: 49.6 KB scene copy, 3 workgroups of 512 lanes per CU without it, 2 with it:
+    // measured 7 % slower than register slots); otherwise the slots are registers
+    bool lds_stack = ra_all.lds_leaf_stack != 0u;
+    if (lds_stack && ra_all.lds_leaf_stack != 2u) {
+        const uint32_t fit_plain = scene_bytes ? (uint32_t)(160u * 1024u / scene_bytes) : wg_per_cu;
+        const uint32_t fit_stack = (uint32_t)(160u * 1024u / with_stack);
+        lds_stack = (fit_stack < wg_per_cu ? fit_stack : wg_per_cu) >= (fit_plain < wg_per_cu ? fit_plain : wg_per_cu);
+    }
+    // few primitives: lock-step leaf list (rt_path.h walk_flat); scenes read from global memory: 16-byte culling nodes
+    // (walk_compact), on request walked near-first through a free-order tree (walk_ordered).  All need the LDS stack.
+    const bool compact = lds_stack && mode == MODE_GLOBAL && L.off_compact != 0u && !ra_all.ref_tree;
+    // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack, 256-lane workgroups of a scene copied to
+    // LDS at 6 waves per SIMD, and must not cost a resident workgroup either
+    const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
+    bool pool = lds_stack && mode == MODE_LDS && threads == 256 && w == 6 && !ra_all.ref_tree;
+    if (const char* env = getenv("TRT_RAY_POOL")) pool = pool && atoi(env) != 0;
+    if (pool) pool = (uint32_t)(160u * 1024u / (with_stack + pool_bytes)) >= wg_per_cu;
+    const size_t lds_bytes = lds_stack ? with_stack + (pool ? pool_bytes : 0u) : scene_bytes;
+    if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
+    pl.mode = mode; pl.threads = threads; pl.w = w; pl.wg_per_cu = wg_per_cu; pl.slots = slots;
+    pl.lds_stack = lds_stack; pl.flat = flat && lds_stack; pl.compact = compact; pl.ordered = compact && L.off_ordered != 0u; pl.pool = pool;
+    pl.lds_bytes = lds_bytes;
+    return pl;
+}
+
+// Name of the kernel that dominates a streamed render of this scene (for profiles and bench.py's roofline line).
+const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra) {
+    return plan_streamed(L, ra).pool ? "trt::stream_pool_kernel" : "trt::stream_sample_kernel";
+}
+
 hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra_all, void* workspace, float* d_accum,
                            unsigned long long* d_counters, bool stats, hipStream_t stream) {
     if (ra_all.rows_local == 0 || cam.width == 0) return hipSuccess;
@@ -297,51 +359,14 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const size_t scene_bytes = scene_lds_bytes(sc.L);
-    const int mode = scene_mode(sc.L);
-    // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies, 512-lane workgroups sharing a big
-    // LDS copy between 8 waves, 8 waves per SIMD for scenes read from global memory
-    const int threads = (mode == MODE_LDS && sc.L.hot_bytes > 20u * 1024u) ? 512 : 256;
-    // LDS scenes: 6 waves per SIMD (80 VGPRs, 21 spilled) beat 7 (72 VGPRs, 38 spilled) by 3 % and 5 (no spills) by 2 % on
-    // Cornell.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box step once the
-    // compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6, 2.29 at 8)
-    int w = mode == MODE_LDS ? 6 : 8;
-    if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
-    if (w < 5) w = 5;
-    if (threads == 512 && w > 6) w = 6;
-    uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
-    // slots of the LDS stack: 4 for tree walks; 6 for the lock-step leaf list, whose t_best stays stale for a whole walk
-    // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12)
-    const bool flat = sc.L.flat_walk && !ra_all.ref_tree;
-    const uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 6u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
-    const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
-    const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
-    // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
-    // resident workgroup (random-spheres: 49.6 KB scene copy, 3 workgroups of 512 lanes per CU without it, 2 with it:
-    // measured 7 % slower than register slots); otherwise the slots are registers
-    bool lds_stack = ra_all.lds_leaf_stack != 0u;
-    if (lds_stack && ra_all.lds_leaf_stack != 2u) {
-        const uint32_t fit_plain = scene_bytes ? (uint32_t)(160u * 1024u / scene_bytes) : wg_per_cu;
-        const uint32_t fit_stack = (uint32_t)(160u * 1024u / with_stack);
-        lds_stack = (fit_stack < wg_per_cu ? fit_stack : wg_per_cu) >= (fit_plain < wg_per_cu ? fit_plain : wg_per_cu);
-    }
-    // few primitives: lock-step leaf list (rt_path.h walk_flat); needs the LDS stack for its postponed leaves
-    // scenes read from global memory: 16-byte culling nodes (rt_path.h walk_compact); it tests postponed leaves against
-    // their exact boxes in the leaf list
-    const bool compact = lds_stack && mode == MODE_GLOBAL && sc.L.off_compact != 0u && !ra_all.ref_tree;
-    const float4* leaf_list = (lds_stack && (flat || compact)) ? sc.blob + sc.L.off_leaf_list : nullptr;
-    const uint4* nodes16 = compact ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_compact) : nullptr;
-    // ... walked near-first through a free-order tree (rt_path.h walk_ordered); the compact fixed-order tree re-traces
-    // the rays whose winner is not safe
-    const uint4* ordered16 = (compact && sc.L.off_ordered != 0u) ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_ordered) : nullptr;
-    // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack, 256-lane workgroups of a scene copied to
-    // LDS at 6 waves per SIMD, and must not cost a resident workgroup either
-    const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-    bool pool = lds_stack && mode == MODE_LDS && threads == 256 && w == 6 && !ra_all.ref_tree;
-    if (const char* env = getenv("TRT_RAY_POOL")) pool = pool && atoi(env) != 0;
-    if (pool) pool = (uint32_t)(160u * 1024u / (with_stack + pool_bytes)) >= wg_per_cu;
-    const size_t lds_bytes = lds_stack ? with_stack + (pool ? pool_bytes : 0u) : scene_bytes;
-    if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
+    const StreamPlan pl = plan_streamed(sc.L, ra_all);
+    const int mode = pl.mode, threads = pl.threads, w = pl.w;
+    const uint32_t wg_per_cu = pl.wg_per_cu, slots = pl.slots;
+    const bool lds_stack = pl.lds_stack, pool = pl.pool;
+    const size_t lds_bytes = pl.lds_bytes;
+    const float4* leaf_list = (pl.flat || pl.compact) ? sc.blob + sc.L.off_leaf_list : nullptr;
+    const uint4* nodes16 = pl.compact ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_compact) : nullptr;
+    const uint4* ordered16 = pl.ordered ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_ordered) : nullptr;
     const uint32_t resident = (uint32_t)cus * wg_per_cu;
     const uint32_t waves_per_wg = (uint32_t)threads / 64u;
     bool first = true;

@@ -17,7 +17,7 @@ base=sys.argv[1]; out={}
 for f in glob.glob(base+"/*/*/*_counter_collection.csv"):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("megakernel", "wavefront_kernel", "stream_sample_kernel")):
+        if any(k in r["Kernel_Name"] for k in ("megakernel", "wavefront_kernel", "stream_sample_kernel", "stream_pool_kernel")):
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k,v in agg.items(): out[k]=sum(v)/len(v)
 json.dump(out, open(base+"/pmc_summary.json","w"), indent=1)
