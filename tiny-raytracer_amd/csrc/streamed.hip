@@ -327,10 +327,10 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
     // few primitives: lock-step leaf list (rt_path.h walk_flat); scenes read from global memory: 16-byte culling nodes
     // (walk_compact), on request walked near-first through a free-order tree (walk_ordered).  All need the LDS stack.
     const bool compact = lds_stack && mode == MODE_GLOBAL && L.off_compact != 0u && !ra_all.ref_tree;
-    // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack, 256-lane workgroups of a scene copied to
-    // LDS at 6 waves per SIMD, and must not cost a resident workgroup either
+    // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack and 256-lane workgroups (LDS scenes at 6
+    // waves per SIMD, global-memory scenes at 8), and must not cost a resident workgroup either
     const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-    bool pool = lds_stack && mode == MODE_LDS && threads == 256 && w == 6 && !ra_all.ref_tree;
+    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w == 6) || (mode == MODE_GLOBAL && w == 8));
     if (const char* env = getenv("TRT_RAY_POOL")) pool = pool && atoi(env) != 0;
     if (pool) pool = (uint32_t)(160u * 1024u / (with_stack + pool_bytes)) >= wg_per_cu;
     const size_t lds_bytes = lds_stack ? with_stack + (pool ? pool_bytes : 0u) : scene_bytes;
@@ -405,7 +405,8 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                 break;
             case MODE_HYBRID: e = launch_pick<MODE_HYBRID, 1, 256>(stats, go); break;
             default:
-                if (w >= 8) e = launch_pick<MODE_GLOBAL, 8, 256>(stats, go);
+                if (w >= 8 && pool) e = stats ? go(stream_pool_kernel<MODE_GLOBAL, true, 8, 256>) : go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256>);
+                else if (w >= 8) e = launch_pick<MODE_GLOBAL, 8, 256>(stats, go);
                 else if (w >= 7) e = launch_pick<MODE_GLOBAL, 7, 256>(stats, go);
                 else if (w >= 6) e = launch_pick<MODE_GLOBAL, 6, 256>(stats, go);
                 else e = launch_pick<MODE_GLOBAL, 1, 256>(stats, go);
