@@ -141,7 +141,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
 // ballot rank - and lanes whose path ended take entries by rank: generation runs once per ~7 rounds with every lane
 // busy, and the stock registers are gone.  Which lane traces which sample changes; every sample's radiance does not
 // (RNG keyed by pixel and sample, radiance stored per sample, folded in order).  Used where the pool costs no resident
-// workgroup (small LDS scene copies).
+// workgroup (small LDS scene copies, scenes in global memory).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kPoolDwords = 9u;         // origin, direction, rng state, radiance slot
 
