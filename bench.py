@@ -25,6 +25,53 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); 6290 measured-achievable
+# VALU issue peak: one wave64 VALU instruction per 2 cycles per SIMD-32 (guides/MI355X_MICROARCH.md, cycle constants:
+# `v_fma_f32` (wave64) 2 cyc), 4 SIMDs x 256 CUs, 2.4 GHz
+N_SIMD = 1024
+CLOCK_GHZ = 2.4
+VALU_PEAK_GINST = N_SIMD * CLOCK_GHZ / 2.0          # 1228.8 G wave-instructions per second
+FRAME_SPP = 4096              # BASELINE configs[3]: the full frame is 4096 spp
+
+
+def step_range(i, spp_per_step, frame_spp=FRAME_SPP):
+    """Sample range of step `i` (warm-up steps included in the numbering) and whether it continues the running sums.
+
+    The frame has `frame_spp` samples per pixel and a step renders `spp_per_step` of them; after the frame's last
+    slice the next step starts a new frame (sums overwritten instead of continued), so any --steps/--warmup works:
+    every step is one slice of the BASELINE frame, exactly the same work whichever frame it belongs to."""
+    if spp_per_step <= 0 or spp_per_step > frame_spp or frame_spp % spp_per_step:
+        raise ValueError(f"--spp-per-step must divide the frame's {frame_spp} spp (got {spp_per_step})")
+    per_frame = frame_spp // spp_per_step
+    k = i % per_frame
+    return k * spp_per_step, (k + 1) * spp_per_step, (0 if k == 0 else 1)
+
+
+def kernel_source_digest():
+    """sha256 over the kernel sources: a PMC profile is only valid for the build it was taken from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "tiny-raytracer_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(key):
+    """profiles/pmc_kernels.json[key]: per-launch PMC means of the dominant kernel (tools/pmc_bench.sh).  Returns
+    (entry, stale): an entry taken from other kernel sources than the ones in the tree is reported as stale and its
+    numbers are not used."""
+    path = os.path.join(ROOT, "profiles", "pmc_kernels.json")
+    if not os.path.exists(path):
+        return None, False
+    with open(path) as f:
+        e = json.load(f).get(key)
+    if e is None:
+        return None, False
+    if e.get("kernel_source_digest") != kernel_source_digest():
+        return e, True
+    return e, False
 
 
 def algorithmic_bytes(c, pixels):
@@ -122,7 +169,11 @@ def main():
             "sphere_grid": lambda w, h: trt.scenes.sphere_grid(100000, w, h)}[args.scene](W, H)
     world, cam = trt.world_from_description(desc)
     scene = world.get_bvh()
-    total_spp = 4096
+    total_spp = FRAME_SPP
+    try:
+        step_range(0, args.spp_per_step)
+    except ValueError as e:
+        sys.exit(str(e))
     if args.backend == "auto":
         args.backend = "streamed"
     backend = {"wavefront": trt.BACKEND_WAVEFRONT, "streamed": trt.BACKEND_STREAMED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
@@ -139,8 +190,9 @@ def main():
     S = args.spp_per_step
 
     def step(i, stats=False, counters=ctr, target=acc):
+        s0, s1, accumulate = step_range(i, S)
         renderer.render_device(cam, scene, target.data_ptr(), stream.cuda_stream, counters.data_ptr(),
-                               sample_begin=i * S, sample_end=(i + 1) * S, accumulate=1, collect_stats=1 if stats else 0,
+                               sample_begin=s0, sample_end=s1, accumulate=accumulate, collect_stats=1 if stats else 0,
                                **band)
 
     def barrier():
@@ -193,19 +245,39 @@ def main():
         bytes_per_launch = (algorithmic_bytes(c, 0) / args.steps + 12 * rows_local * W) / launches_per_step
         avg_ms = sum(launch_ms) / len(launch_ms) / launches_per_step
         achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(prof):
-            with open(prof) as f:
-                pj = json.load(f)
-            key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}"
-            traffic = pj.get(key, {}).get("hbm_bytes_per_launch")
-        roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_ms": round(avg_ms, 4),
-                    "launches_per_step": launches_per_step,
-                    "bytes_per_ray": round(algorithmic_bytes(c, 0) / max(c["rays"], 1), 2),
-                    "rays_per_sample": round(c["rays"] / max(c["samples"], 1), 3)}
+        algorithmic = {"bytes_per_launch": int(bytes_per_launch), "GBps": round(achieved, 2),
+                       "ratio_to_hbm_peak": round(achieved / HBM_PEAK_GBPS, 5),
+                       "bytes_per_ray": round(algorithmic_bytes(c, 0) / max(c["rays"], 1), 2),
+                       "note": "SURVEY 8(d): bytes the reference-order traversal would read per launch / launch time. NOT a "
+                               "physical fraction: the scene is served from LDS/SGPRs/L2, so it may exceed 1"}
+        # The binding resource is VALU issue: instruction counts and physical HBM bytes per launch of the
+        # dominant kernel come from the rocprofv3 PMC passes kept under profiles/ (tools/pmc_bench.sh), the launch time
+        # is the one measured live above.  A profile of other kernel sources is refused.
+        key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}"
+        prof, stale = pmc_profile(key)
+        roofline = {"bound": "valu", "kernel": kernel_name, "achieved": None, "peak": round(VALU_PEAK_GINST, 1),
+                    "unit": "G wave64 VALU instructions/s", "frac": None, "traffic": None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                    "rays_per_sample": round(c["rays"] / max(c["samples"], 1), 3),
+                    "pmc_key": key, "pmc_stale": stale, "algorithmic": algorithmic}
+        if prof is not None and not stale and world_size == 1:
+            insts = prof["SQ_INSTS_VALU"]
+            valu_rate = insts / (avg_ms * 1e-3) / 1e9
+            lanes = prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"] * 16.0 if prof.get("SQ_ACTIVE_INST_VALU") else None
+            hbm = prof["hbm_bytes_per_launch"]
+            roofline.update({
+                "achieved": round(valu_rate, 1), "frac": round(valu_rate / VALU_PEAK_GINST, 4), "traffic": int(hbm),
+                "valu_wave_insts_per_launch": int(insts),
+                "valu_wave_insts_per_ray": round(insts * launches_per_step * args.steps / max(total_rays, 1), 2),
+                "cycles_per_valu_inst_per_simd": round(avg_ms * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
+                "peak_cycles_per_valu_inst_per_simd": 2.0,
+                "mean_active_lanes": round(lanes, 1) if lanes else None,
+                "lane_slot_frac": round(valu_rate / VALU_PEAK_GINST * lanes / 64.0, 4) if lanes else None,
+                "salu_insts_per_launch": int(prof.get("SQ_INSTS_SALU", 0)),
+                "hbm_physical_GBps": round(hbm / (avg_ms * 1e-3) / 1e9, 1),
+                "hbm_physical_frac": round(hbm / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "pmc_source": prof.get("source")})
+            assert roofline["frac"] <= 1.0 and roofline["hbm_physical_frac"] <= 1.0, "a roofline fraction above 1 is a bug"
 
     cpu = None
     if rank == 0 and world_size == 1 and args.cpu_seconds > 0:

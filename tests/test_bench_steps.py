@@ -1,0 +1,61 @@
+"""bench.py's step arithmetic on CPU: any --steps/--warmup must stay inside the renderer's sample range
+(round 1 crashed on the driver's `--steps 20 --warmup 5`: step 16 asked for samples 4096..4352 of a 4096-spp frame,
+which to_render_args in capi.hip rejects)."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("steps,warmup", [(4, 1), (20, 5), (40, 10), (1, 0), (16, 0), (17, 16), (1000, 333)])
+@pytest.mark.parametrize("spp", [256, 64, 16, 4096, 1])
+def test_every_step_is_a_slice_of_the_frame(bench, steps, warmup, spp):
+    frame = bench.FRAME_SPP
+    seen_in_frame = 0
+    for i in range(warmup + steps):
+        s0, s1, accumulate = bench.step_range(i, spp)
+        assert 0 <= s0 < s1 <= frame, "what capi.hip to_render_args accepts: begin <= end <= samples_per_pixel"
+        assert s1 - s0 == spp, "every step is the same amount of work"
+        # a frame starts by overwriting the sums and every later slice continues them, in order
+        assert accumulate == (0 if s0 == 0 else 1)
+        if s0 == 0:
+            seen_in_frame = 0
+        assert s0 == seen_in_frame
+        seen_in_frame = s1
+
+
+def test_step_size_must_divide_the_frame(bench):
+    for bad in (0, -1, 3, 4097, 8192, 1000):
+        with pytest.raises(ValueError):
+            bench.step_range(0, bad)
+
+
+def test_library_accepts_every_range_bench_produces(bench, trt):
+    """The C ABI's own validation (no GPU needed: argument errors come before the device check would matter)."""
+    import ctypes as C
+    desc = trt.scenes.cornell(64, 64)
+    world, cam = trt.world_from_description(desc)
+    scene = world.get_bvh()
+    r = trt.Renderer(bench.FRAME_SPP, 1, 50, False, desc["background"], seed=1)
+    for i in (0, 15, 16, 24, 39, 49):
+        s0, s1, acc = bench.step_range(i, 256)
+        p = r.params(sample_begin=s0, sample_end=s1, accumulate=acc)
+        name = trt.lib.trt_dominant_kernel(scene._h, C.byref(cam.pod), C.byref(p))      # runs to_render_args; "" on a rejected range
+        assert name.decode() != ""
+    p = r.params(sample_begin=4096, sample_end=4352, accumulate=1)                       # round 1's failing request
+    assert trt.lib.trt_dominant_kernel(scene._h, C.byref(cam.pod), C.byref(p)).decode() == ""
+
+
+def test_kernel_source_digest_is_stable(bench):
+    assert bench.kernel_source_digest() == bench.kernel_source_digest()
+    assert len(bench.kernel_source_digest()) == 16

@@ -15,6 +15,7 @@
 
 #include "kernels.h"
 #include "rt_path.h"
+#include "trt_pow.h"
 
 namespace trt {
 
@@ -201,22 +202,14 @@ hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in,
 // Imager finalisation on the device: Color::gamma_correction + From<Color> for Rgb<u8>
 // (utils/image.rs:92-111): c^(1/gamma), clamp to [0, 0.999], * 255, truncate; NaN -> 0.  Elementwise and HBM-bound:
 // 12 bytes read + 3 written per pixel, four channels per lane (one 16-byte load, one 4-byte store).
-// c^(1/gamma) is evaluated in f64 and rounded to f32, which agrees with a correctly rounded powf (the host's and the
-// oracle's libm) except where powf itself is off by an ulp; frames are compared with a +-1 LSB allowance - this step
-// is outside the path's parity target, the linear sums are the product.
+// c^(1/gamma) is trt-math v1's powf (trt_pow.h): the same function the host form (scene_host.cpp tonemap_u8) and the CPU
+// oracle evaluate, so the three u8 frames are equal byte for byte (tests compare them exactly).
 // ------------------------------------------------------------------------------------------------
-TRT_DEV uint32_t quantise_channel(float c, double inv_gamma) {
-    float g = (float)pow((double)c, inv_gamma);
-    if (g < 0.000f) g = 0.000f;
-    if (g > 0.999f) g = 0.999f;
-    const float s = g * 255.0f;
-    if (!(s == s) || s <= 0.0f) return 0u;
-    return s >= 255.0f ? 255u : (uint32_t)s;
-}
+TRT_DEV uint32_t quantise_channel(float c, float inv_gamma) { return (uint32_t)tm_quantise_channel(c, inv_gamma); }
 
 __global__ __launch_bounds__(256) void tonemap_u8_kernel(const float* __restrict__ accum, unsigned long long n_channels,
                                                          float inv_gamma, uint8_t* __restrict__ rgb, uint32_t vectorised) {
-    const double ig = (double)inv_gamma;
+    const float ig = inv_gamma;
     const unsigned long long i4 = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x) * 4ull;
     if (i4 >= n_channels) return;
     if (vectorised && i4 + 4ull <= n_channels) {

@@ -3,6 +3,7 @@
 // -ffp-contract=off so the f32 values it precomputes (boxes, quad planes, camera basis) are the
 // ones the reference's constructors produce.
 #include "scene.h"
+#include "trt_pow.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -581,18 +582,10 @@ void camera_init(trt_camera& out, float focus_distance, float defocus_angle_deg,
 // Imager: set_pixel applies gamma (imager.rs:52-53, image.rs:38-44,92-98); RgbImage conversion clamps
 // to [0, 0.999], scales by 255 and truncates (image.rs:101-111; Rust's `as u8` saturates, NaN -> 0).
 void tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* rgb) {
-    const float inv_gamma = 1.0f / gamma;
-    for (size_t i = 0; i < (size_t)npixels * 3; i++) {
-        float c = powf(accum[i], inv_gamma);
-        if (c < 0.000f) c = 0.000f;
-        if (c > 0.999f) c = 0.999f;
-        float s = c * 255.0f;
-        uint8_t q;
-        if (!(s == s) || s <= 0.0f) q = 0;
-        else if (s >= 255.0f) q = 255;
-        else q = (uint8_t)s;
-        rgb[i] = q;
-    }
+    const float inv_gamma = 1.0f / gamma;                                   // image.rs:94-96
+    for (size_t i = 0; i < (size_t)npixels * 3; i++) rgb[i] = tm_quantise_channel(accum[i], inv_gamma);
 }
+
+float powf_v1(float x, float y) { return tm_powf(x, y); }
 
 }  // namespace trt
