@@ -158,6 +158,11 @@ extern "C" {
 
     pub fn trt_render(s: *mut trt_scene, cam: *const trt_camera, p: *const trt_render_params, accum: *mut f32,
                       stats: *mut trt_stats) -> c_int;
+    pub fn trt_render_multi(s: *mut trt_scene, cam: *const trt_camera, p: *const trt_render_params, devices: *const c_int,
+                            ndev: u32, accum: *mut f32, stats: *mut trt_stats) -> c_int;
+    pub fn trt_render_multi_device(s: *mut trt_scene, cam: *const trt_camera, p: *const trt_render_params,
+                                   devices: *const c_int, ndev: u32, d_accum: *mut f32, stats: *mut trt_stats) -> c_int;
+    pub fn trt_band_rows_local(height: u32, ndev: u32, rank: u32, rows_local: *mut u32) -> c_int;
     pub fn trt_render_device(s: *mut trt_scene, cam: *const trt_camera, p: *const trt_render_params, d_accum: *mut f32,
                              d_counters: *mut u64, stream: *mut c_void) -> c_int;
     pub fn trt_sample_batch(s: *mut trt_scene, input: *const trt_sample_point, n: u32, out: *mut trt_sampled_color,
@@ -165,6 +170,8 @@ extern "C" {
     pub fn trt_tonemap_u8(accum: *const f32, npixels: u32, gamma: f32, rgb: *mut u8) -> c_int;
     pub fn trt_tonemap_u8_device(d_accum: *const f32, npixels: u32, gamma: f32, d_rgb: *mut u8, stream: *mut c_void) -> c_int;
     pub fn trt_streamed_chunk_spp(width: u32, rows: u32) -> u32;
+    pub fn trt_kernel_timing_begin() -> c_int;
+    pub fn trt_kernel_timing_end(total_ms: *mut f64, launches: *mut u32) -> c_int;
 
     pub fn trt_dominant_kernel(s: *const trt_scene, cam: *const trt_camera, p: *const trt_render_params) -> *const c_char;
 

@@ -158,10 +158,33 @@ typedef struct {
  * rows_local or height.  Gamma/quantisation is not applied: see trt_tonemap_u8. */
 int trt_render(trt_scene *s, const trt_camera *cam, const trt_render_params *p, float *accum, trt_stats *stats);
 
+/* Renderer::render over several GPUs of one node: still ONE call that returns the whole frame (renderer.rs:37-79;
+ * src/main.rs:19).  The scene is replicated, the image is cut into bands of 16 rows dealt round-robin over the shards
+ * (band b -> shard b % ndev), one host thread per shard drives its device, and each finished band is copied straight to its
+ * place in `accum` (HOST buffer, height*width*3 f32; read first when p->accumulate is set).  The frame is bit-identical for
+ * every ndev and equals trt_render's: the RNG is keyed by the image pixel and every pixel is folded in sample order.
+ * `devices`: ndev device ordinals (a device may appear more than once: its shards then run concurrently on it), or NULL
+ * for 0..ndev-1; ndev == 0 means every visible device.  p->band_rows must be 0.  stats (may be NULL): counters summed over
+ * the shards, kernel_ms of the slowest one. */
+int trt_render_multi(trt_scene *s, const trt_camera *cam, const trt_render_params *p, const int *devices, uint32_t ndev,
+                     float *accum, trt_stats *stats);
+/* The same with the frame gathered into HBM: `d_accum` is a buffer of height*width*3 f32 on devices[0] (device 0 when
+ * `devices` is NULL); every shard sends its bands there with one peer copy per band (xGMI between the GPUs of a node).
+ * Synchronous: the frame is complete when the call returns. */
+int trt_render_multi_device(trt_scene *s, const trt_camera *cam, const trt_render_params *p, const int *devices,
+                            uint32_t ndev, float *d_accum, trt_stats *stats);
+/* Rows of an image of `height` rows that shard `rank` of `ndev` owns under that band layout (host arithmetic only). */
+int trt_band_rows_local(uint32_t height, uint32_t ndev, uint32_t rank, uint32_t *rows_local);
+
 /* Same, on buffers already resident in HBM.  `d_accum`: device pointer, rows*width*3 f32.
  * `d_counters`: device pointer to 16 uint64 (zeroed by the caller; [0..6] = trt_stats' first seven
  * fields, [8..11] = wave_trips) or NULL.  `stream`: a hipStream_t (NULL = default stream).  Asynchronous: returns after
- * enqueueing; the caller synchronises the stream. */
+ * enqueueing; the caller synchronises the stream.
+ *
+ * Concurrency (all render entry points): a scene is immutable once created and may be rendered by several host threads
+ * and on several streams at the same time; every render takes private device scratch from a pool on the scene handle
+ * (at most 8 scratch buffers per device: further concurrent renders queue behind running ones on the device).
+ * trt_scene_destroy must not run while a render of that scene is still being enqueued. */
 int trt_render_device(trt_scene *s, const trt_camera *cam, const trt_render_params *p, float *d_accum,
                       uint64_t *d_counters, void *stream);
 
@@ -182,6 +205,12 @@ int trt_tonemap_u8_device(const float *d_accum, uint32_t npixels, float gamma, u
 /* Samples per pixel the streamed backend traces per kernel launch for an image of this size (it splits longer sample
  * ranges into such chunks; one chunk = one `trt::stream_sample_kernel` launch + one fold launch). */
 uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows);
+
+/* Measurement aid: between _begin and _end every launch of a render's dominant kernel (streamed backend: the sample
+ * kernel, not the fold) is bracketed by HIP events on the stream it is launched on; _end waits for them and returns the
+ * summed device time and the number of launches.  Process-wide; meant for one rendering thread at a time. */
+int trt_kernel_timing_begin(void);
+int trt_kernel_timing_end(double *total_ms, uint32_t *launches);
 
 /* Name of the GPU kernel that dominates a render of this scene with these settings ("trt::stream_pool_kernel", ...): what
  * a kernel trace of the call shows, for profiles and benchmark records.  "" on invalid arguments. */

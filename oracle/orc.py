@@ -94,6 +94,7 @@ def _load():
         "orc_sample_batch": (None, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, Vec3, C.c_uint32, P(Stats)]),
         "orc_tonemap_u8": (None, [C.c_void_p, C.c_uint32, C.c_float, C.c_void_p]),
         "orc_gamma_correct": (C.c_float, [C.c_float, C.c_float]),
+        "orc_powf": (C.c_float, [C.c_float, C.c_float]),
         "orc_sphere_hit": (C.c_int, [Vec3, C.c_float, P(Ray), C.c_float, C.c_float, P(HitRecord)]),
         "orc_quad_hit": (C.c_int, [Vec3, Vec3, Vec3, P(Ray), C.c_float, C.c_float, P(HitRecord)]),
         "orc_aabb_intersect": (C.c_int, [P(Aabb), P(Ray), C.c_float, C.c_float]),

@@ -110,6 +110,7 @@ void orc_sample_batch(orc_world *, const orc_sample_point *in, uint32_t n, orc_s
 
 /* ---- Imager finalisation + Image/Color (imager.rs:52-53, utils/image.rs:92-111) ---- */
 void orc_tonemap_u8(const float *accum, uint32_t npixels, float gamma, uint8_t *rgb);
+float orc_powf(float x, float y);                 /* trt-math v1 powf (libm powf when orc_set_use_libm(1)) */
 float orc_gamma_correct(float c, float gamma);    /* Color::gamma_correction, one channel */
 
 /* ---- unit entry points for the reference's known-answer tests ---- */

@@ -1,0 +1,78 @@
+"""BASELINE configs[4] at FULL size: the 100 000-sphere scene (200 001-node reference BVH, walked from global memory) at
+3840x2160, depth 50.  Round 1 only ever rendered this scene from bench.py; here it is under test:
+
+ * oracle parity on the whole 3840x2160 frame at 1 spp (8.3 M samples; the oracle needs well under a minute on the box's
+   host cores), bit for bit, plus the ray count;
+ * oracle parity on 16-row bands at 2 spp rendered AS bands (trt_render_params band layout), top / middle / bottom;
+ * the counting kernel's node / sphere / shade counters against the oracle's on those bands (reference-order walk);
+ * default walk (16-byte f16 culling nodes) vs the opt-in near-first walk (TRT_ORDERED_WALK=1) vs 32-byte nodes: frames
+   and ray counts identical on the full frame;
+ * size-independent properties at 4 spp: progressive passes == one pass; multi-shard render == one render."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W, H, DEPTH = 3840, 2160, 50
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.fixture(scope="module")
+def cfg5(trt):
+    return trt.scenes.sphere_grid(100000, W, H)
+
+
+def test_cfg5_full_frame_bit_exact_against_the_oracle(trt, orc, cfg5, monkeypatch):
+    desc = cfg5
+    ow, ocam = orc.world_from_description(desc)
+    cpu, cst = orc.render(ow, ocam, 1, DEPTH, desc["background"], seed=1, nthreads=16)
+    frames = {}
+    for name, env in (("default", {}), ("ordered", {"TRT_ORDERED_WALK": "1"}), ("nodes32", {"TRT_COMPACT_NODES": "0"})):
+        for k in ("TRT_ORDERED_WALK", "TRT_COMPACT_NODES"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)                                 # read when the scene is compiled
+        pw, pcam = trt.world_from_description(desc)
+        info = pw.get_bvh().info()
+        assert info["num_nodes"] == 200001 and info["num_spheres"] == 100001 and info["lds_bytes"] == 0
+        r = trt.Renderer(1, 1, DEPTH, False, desc["background"], seed=1)
+        frames[name] = r.render(pcam, pw).data
+        assert r.last_stats["rays"] == cst["rays"] and r.last_stats["samples"] == W * H, name
+        assert np.array_equal(bits(frames[name]), bits(cpu)), f"{name} walk differs from the oracle on the cfg5 frame"
+    assert np.isfinite(frames["default"]).all() and frames["default"].mean() > 0.1
+
+
+def test_cfg5_bands_and_counters(trt, orc, cfg5):
+    desc = cfg5
+    pw, pcam = trt.world_from_description(desc)
+    ow, ocam = orc.world_from_description(desc)
+    r = trt.Renderer(2, 1, DEPTH, False, desc["background"], seed=7)
+    n_bands = H // 16
+    for band in (0, 1, n_bands // 2, n_bands - 1):
+        cpu, cst = orc.render(ow, ocam, 2, DEPTH, desc["background"], seed=7, nthreads=16, row_begin=16 * band, row_end=16 * band + 16)
+        want = cpu[16 * band:16 * band + 16]
+        # the band as one rank of n_bands would render it: local rows 0..15 = image rows 16*band..
+        got = r.render(pcam, pw, band_rows=16, band_stride=n_bands, band_offset=band, rows_local=16)
+        assert np.array_equal(bits(got.data), bits(want)), band
+        assert r.last_stats["rays"] == cst["rays"]
+        counted = r.render(pcam, pw, collect_stats=True, band_rows=16, band_stride=n_bands, band_offset=band, rows_local=16)
+        assert np.array_equal(bits(counted.data), bits(want)), band
+        for k in ("samples", "rays", "node_tests", "sphere_tests", "shades"):
+            assert r.last_stats[k] == cst[k], (band, k)
+
+
+def test_cfg5_progressive_and_sharded_renders_equal_one_pass(trt, cfg5):
+    desc = cfg5
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(4, 1, DEPTH, False, desc["background"], seed=3)
+    whole = r.render(pcam, pw).data
+    rays = r.last_stats["rays"]
+    acc = np.zeros((H, W, 3), np.float32)
+    r.render(pcam, pw, accum=acc, sample_begin=0, sample_end=1)
+    r.render(pcam, pw, accum=acc, sample_begin=1, sample_end=4, accumulate=1)
+    assert np.array_equal(bits(acc), bits(whole))
+    sharded = r.render_multi(pcam, pw, devices=[0, 0, 0])
+    assert np.array_equal(bits(sharded.data), bits(whole)) and r.last_stats["rays"] == rays

@@ -1,0 +1,164 @@
+"""Multi-GPU behind the C ABI (trt_render_multi: renderer.rs:37-79 is ONE call that returns the whole Image) and
+concurrent renders of one scene handle.
+
+A GPU box has one MI355X, so the N-shard layout is exercised with the same ordinal listed several times: every shard
+is driven by its own host thread on its own stream with its own device buffers, renders its round-robin bands and
+copies them to their place in the frame - everything the 8-GPU run does except that the copies stay on one device.
+Shards of one device render the same scene handle concurrently, which is exactly the case the per-render workspace
+pool (capi.hip workspace_acquire) exists for."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("scene,w,h", [("cornell", 200, 150), ("random_spheres", 160, 90)])
+def test_render_multi_equals_render_for_every_shard_count(trt, orc, scene, w, h):
+    desc = getattr(trt.scenes, scene)(w, h)                       # h is not a multiple of 16: the last band is ragged
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(8, 1, 10, False, desc["background"], seed=5)
+    one = r.render(pcam, pw)
+    rays = r.last_stats["rays"]
+    ow, ocam = orc.world_from_description(desc)
+    cpu, cst = orc.render(ow, ocam, 8, 10, desc["background"], seed=5, nthreads=8)
+    assert np.array_equal(bits(one.data), bits(cpu)) and rays == cst["rays"]
+    for devices in ([0], [0, 0], [0, 0, 0], [0] * 8, [0] * 13, None):     # 13 shards > 10 bands: some shards own nothing
+        img = r.render_multi(pcam, pw, devices=devices)
+        assert np.array_equal(bits(img.data), bits(cpu)), devices
+        assert r.last_stats["rays"] == rays and r.last_stats["samples"] == 8 * w * h, devices
+    # counting variant through the multi entry: the shards' counters add up to the oracle's
+    r.render_multi(pcam, pw, devices=[0, 0, 0], collect_stats=True)
+    for k in ("samples", "rays", "node_tests", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
+        assert r.last_stats[k] == cst[k], k
+
+
+def test_render_multi_progressive_passes_and_backends(trt):
+    desc = trt.scenes.cornell(128, 100)
+    pw, pcam = trt.world_from_description(desc)
+    for backend in (trt.BACKEND_STREAMED, trt.BACKEND_MEGAKERNEL, trt.BACKEND_WAVEFRONT):
+        r = trt.Renderer(12, 1, 8, False, desc["background"], seed=2, backend=backend)
+        whole = r.render(pcam, pw).data
+        acc = np.zeros((100, 128, 3), np.float32)
+        r.render_multi(pcam, pw, devices=[0, 0], accum=acc, sample_begin=0, sample_end=5)
+        r.render_multi(pcam, pw, devices=[0, 0, 0], accum=acc, sample_begin=5, sample_end=12, accumulate=1)
+        assert np.array_equal(bits(acc), bits(whole)), backend
+
+
+def test_render_multi_device_gathers_into_hbm(trt):
+    import torch
+    desc = trt.scenes.cornell(256, 208)
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(6, 1, 12, False, desc["background"], seed=9)
+    want = r.render(pcam, pw).data
+    frame = torch.full((208, 256, 3), -1.0, device="cuda:0")
+    for devices in ([0], [0, 0], [0] * 4):
+        frame.fill_(-1.0)
+        torch.cuda.synchronize()
+        r.render_multi(pcam, pw, devices=devices, d_accum_ptr=frame.data_ptr())
+        assert np.array_equal(bits(frame.cpu().numpy()), bits(want)), devices
+    # continuing sums that live in HBM
+    frame.zero_()
+    torch.cuda.synchronize()
+    r.render_multi(pcam, pw, devices=[0, 0], d_accum_ptr=frame.data_ptr(), sample_begin=0, sample_end=2)
+    r.render_multi(pcam, pw, devices=[0, 0, 0], d_accum_ptr=frame.data_ptr(), sample_begin=2, sample_end=6, accumulate=1)
+    assert np.array_equal(bits(frame.cpu().numpy()), bits(want))
+
+
+def test_render_multi_rejects_bad_arguments(trt):
+    desc = trt.scenes.cornell(64, 64)
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(2, 1, 4, False, desc["background"])
+    with pytest.raises(trt.TinyRTError) as e:
+        r.render_multi(pcam, pw, devices=[0, 99])
+    assert e.value.code == -1
+    with pytest.raises(trt.TinyRTError) as e:
+        r.render_multi(pcam, pw, devices=[0], band_rows=16, band_stride=1, band_offset=0, rows_local=64)
+    assert e.value.code == -1
+    with pytest.raises(trt.TinyRTError) as e:
+        r.render_multi(pcam, pw, devices=[0], sample_begin=3, sample_end=2)
+    assert e.value.code == -1
+
+
+@pytest.mark.parametrize("backend", ["streamed", "wavefront"])
+def test_concurrent_renders_of_one_scene_equal_serial_ones(trt, backend):
+    """Round 1 cached ONE device workspace (radiance records + batch counter) on the scene handle, shared by every render:
+    two renders of one scene at the same time overwrote each other's records.  Now every render owns its scratch until
+    its last kernel has run.  Six host threads render the same scene handle at once, each with its own seed and sample
+    count (ctypes releases the GIL during the call; trt_render uses a stream of its own); every frame must equal the one
+    rendered alone."""
+    be = {"streamed": trt.BACKEND_STREAMED, "wavefront": trt.BACKEND_WAVEFRONT}[backend]
+    desc = trt.scenes.cornell(384, 384)
+    pw, pcam = trt.world_from_description(desc)
+    scene = pw.get_bvh()
+    jobs = [(seed, 4 + 2 * (seed % 3)) for seed in range(1, 7)]
+    serial = {}
+    for seed, spp in jobs:
+        serial[seed] = trt.Renderer(spp, 1, 12, False, desc["background"], seed=seed, backend=be).render(pcam, scene).data.copy()
+    for _ in range(3):
+        got, errors = {}, []
+
+        def work(seed, spp):
+            try:
+                got[seed] = trt.Renderer(spp, 1, 12, False, desc["background"], seed=seed, backend=be).render(pcam, scene).data
+            except Exception as ex:                                  # noqa: BLE001 - reported below
+                errors.append(ex)
+
+        threads = [threading.Thread(target=work, args=j) for j in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for seed, _ in jobs:
+            assert np.array_equal(bits(got[seed]), bits(serial[seed])), (backend, seed)
+
+
+def test_concurrent_device_renders_on_two_streams(trt):
+    """trt_render_device is asynchronous on the caller's stream: two renders of one scene enqueued on two streams (no host
+    synchronisation in between) and a third that needs a LARGER workspace while those may still run."""
+    import torch
+    dev = torch.device("cuda:0")
+    desc = trt.scenes.cornell(512, 512)
+    pw, pcam = trt.world_from_description(desc)
+    scene = pw.get_bvh()
+    big_desc = trt.scenes.cornell(1024, 1024)
+    _, big_cam = trt.world_from_description(big_desc)               # same world, larger image -> larger scratch
+    ra, rb = trt.Renderer(8, 1, 16, False, desc["background"], seed=3), trt.Renderer(8, 1, 16, False, desc["background"], seed=4)
+    want_a, want_b = ra.render(pcam, scene).data, rb.render(pcam, scene).data
+    want_big = ra.render(big_cam, scene).data
+    s1, s2, s3 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.zeros((512, 512, 3), device=dev)
+    b = torch.zeros((512, 512, 3), device=dev)
+    big = torch.zeros((1024, 1024, 3), device=dev)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        ra.render_device(pcam, scene, a.data_ptr(), s1.cuda_stream)
+        rb.render_device(pcam, scene, b.data_ptr(), s2.cuda_stream)
+        ra.render_device(big_cam, scene, big.data_ptr(), s3.cuda_stream)
+        ra.render_device(pcam, scene, a.data_ptr(), s1.cuda_stream)          # again on the same stream, back to back
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(a.cpu().numpy()), bits(want_a))
+    assert np.array_equal(bits(b.cpu().numpy()), bits(want_b))
+    assert np.array_equal(bits(big.cpu().numpy()), bits(want_big))
+
+
+def test_kernel_timing_brackets_the_dominant_kernel(trt):
+    import ctypes as C
+    desc = trt.scenes.cornell(256, 256)
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(16, 1, 8, False, desc["background"])
+    trt._lib.check(trt.lib.trt_kernel_timing_begin())
+    r.render(pcam, pw)
+    r.render(pcam, pw)
+    ms, n = C.c_double(0.0), C.c_uint32(0)
+    trt._lib.check(trt.lib.trt_kernel_timing_end(C.byref(ms), C.byref(n)))
+    assert n.value == 2 and 0.0 < ms.value < 1000.0
+    r.render(pcam, pw)                                              # disabled again: nothing recorded
+    trt._lib.check(trt.lib.trt_kernel_timing_end(C.byref(ms), C.byref(n)))
+    assert n.value == 0

@@ -171,9 +171,10 @@ def test_leaf_slots_are_scheduling_only(trt, monkeypatch, scene):
     assert r.last_stats["rays"] == ref_stats["rays"]
 
 
-def test_device_tonemap_matches_host_form(trt):
-    """SURVEY 8 f1 on the device: the frame is rendered, gamma-corrected and quantised without leaving HBM; against the
-    host form (libm powf, = the oracle's) a channel may differ by one LSB where powf is not correctly rounded."""
+def test_device_tonemap_is_bit_exact_against_the_oracle(trt, orc):
+    """SURVEY 8 f1 on the device: the frame is rendered, gamma-corrected and quantised without leaving HBM.  Byte output:
+    the device frame must EQUAL the oracle's (orc_tonemap_u8) - both evaluate trt-math v1's powf (trt_pow.h / rt_oracle.c
+    m_powf), as does the host form."""
     import torch
     dev = torch.device("cuda:0")
     desc = trt.scenes.cornell(301, 203)                                    # odd sizes: the 4-channel vector path has a tail
@@ -183,20 +184,32 @@ def test_device_tonemap_matches_host_form(trt):
     stream = torch.cuda.current_stream()
     r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream)
     rgb = torch.zeros((203, 301, 3), dtype=torch.uint8, device=dev)
-    trt.tonemap_u8_device(acc.data_ptr(), 203 * 301, rgb.data_ptr(), 2.2, stream.cuda_stream)
+    for gamma in (2.2, 1.0, 1.8, 0.45):
+        trt.tonemap_u8_device(acc.data_ptr(), 203 * 301, rgb.data_ptr(), gamma, stream.cuda_stream)
+        torch.cuda.synchronize()
+        want = orc.tonemap_u8(acc.cpu().numpy(), gamma)
+        assert np.array_equal(rgb.cpu().numpy(), want), gamma
+        assert np.array_equal(trt.Image(acc.cpu().numpy(), gamma).to_u8(), want), gamma
+    # a dense sweep of channel values incl. every special case, through the same kernel: 3 M floats
+    rng = np.random.default_rng(11)
+    vals = np.concatenate([rng.random(1_000_000).astype(np.float32), np.exp(rng.uniform(-100, 90, 1_000_000)).astype(np.float32),
+                           rng.integers(0, 2**32, 999_000, dtype=np.uint32).view(np.float32),            # any bit pattern
+                           np.resize(np.array([np.nan, -1.0, 0.0, -0.0, 1e-9, 0.5, 0.999, 1.0, 7.0, np.inf, -np.inf, 1e-45, 3.4e38], np.float32), 1000)])
+    d_vals = torch.from_numpy(vals).to(dev)
+    d_out = torch.zeros(vals.size, dtype=torch.uint8, device=dev)
+    trt.tonemap_u8_device(d_vals.data_ptr(), vals.size // 3, d_out.data_ptr(), 2.2, stream.cuda_stream)
     torch.cuda.synchronize()
-    host = trt.Image(acc.cpu().numpy()).to_u8()
-    d = np.abs(rgb.cpu().numpy().astype(np.int16) - host.astype(np.int16))
-    assert d.max() <= 1 and (d != 0).mean() < 1e-3
-    # special values, unaligned buffers (scalar path): NaN -> 0, negative -> 0, >= 1 -> 254, inf -> 254
+    with np.errstate(all="ignore"):
+        assert np.array_equal(d_out.cpu().numpy(), orc.tonemap_u8(vals.reshape(1, -1, 3), 2.2).ravel())
+    # unaligned buffers (scalar path): NaN -> 0, negative -> 0, >= 1 -> 254, inf -> 254
     special = torch.tensor([float("nan"), -1.0, 0.0, 1e-9, 0.5, 0.999, 1.0, 7.0, float("inf"), 0.25, 0.125, 0.73], device=dev)
     buf = torch.zeros(16, device=dev)
     buf[1:13] = special
     out = torch.zeros(16, dtype=torch.uint8, device=dev)
     trt.tonemap_u8_device(buf.data_ptr() + 4, 4, out.data_ptr() + 1, 2.2, stream.cuda_stream)
     torch.cuda.synchronize()
-    ref = trt.Image(special.cpu().numpy().reshape(1, 4, 3)).to_u8().ravel()
-    assert np.abs(out.cpu().numpy()[1:13].astype(np.int16) - ref.astype(np.int16)).max() <= 1
+    ref = orc.tonemap_u8(special.cpu().numpy().reshape(1, 4, 3), 2.2).ravel()
+    assert np.array_equal(out.cpu().numpy()[1:13], ref)
     assert list(out.cpu().numpy()[[1, 2, 3, 7, 8, 9]]) == [0, 0, 0, 254, 254, 254]
 
 

@@ -118,6 +118,12 @@ def test_tonemap_matches_oracle_and_reference_rules(trt, orc):
     assert np.array_equal(mine, ref)
     assert mine[0, 0].tolist() == [0, 0, 254]                      # NaN -> 0 (image.rs:106-108), clamp at 0.999
     assert mine.max() == 254
+    # any bit pattern, several gammas: host form (trt_pow.h) == oracle (rt_oracle.c m_powf), byte for byte
+    vals = np.concatenate([rng.integers(0, 2**32, 299_997, dtype=np.uint32).view(np.float32),
+                           np.exp(rng.uniform(-100, 90, 300_000)).astype(np.float32), rng.random(300_000).astype(np.float32)])
+    with np.errstate(all="ignore"):
+        for gamma in (2.2, 1.0, 1.8, 0.45, 3.0):
+            assert np.array_equal(trt.Image(vals.reshape(1, -1, 3), gamma).to_u8(), orc.tonemap_u8(vals.reshape(1, -1, 3), gamma)), gamma
 
 
 def test_band_layout_covers_image_once(trt):
@@ -279,3 +285,21 @@ def test_header_is_valid_c_and_the_c_example_fails_loudly_without_gpu(trt, tmp_p
         assert r.returncode == 0 and "rays in" in r.stdout and os.path.exists(tmp_path / "minimal.ppm")
     else:
         assert r.returncode == 1 and "no HIP device visible" in r.stderr
+
+
+def test_c_band_layout_equals_the_python_one(trt):
+    """trt_render_multi (C, one host thread per device) and tiles.py (one process per GPU over torch.distributed) must cut
+    the image the same way: 16-row bands dealt round-robin."""
+    from importlib import import_module
+    tiles = import_module("tiny-raytracer_amd.tiles")
+    for height in (1, 15, 16, 17, 150, 1080, 2048, 2160):
+        for ndev in (1, 2, 3, 4, 7, 8, 13):
+            total = 0
+            for rank in range(ndev):
+                rows = C.c_uint32(0)
+                assert trt.lib.trt_band_rows_local(height, ndev, rank, C.byref(rows)) == 0
+                assert rows.value == tiles.band_layout(height, ndev, rank)["rows_local"], (height, ndev, rank)
+                total += rows.value
+            assert total == height
+    assert trt.lib.trt_band_rows_local(100, 0, 0, C.byref(C.c_uint32())) == -1
+    assert trt.lib.trt_band_rows_local(100, 2, 2, C.byref(C.c_uint32())) == -1

@@ -199,3 +199,35 @@ def test_own_math_vs_libm_mode_agree_statistically(orc, trt):
     finally:
         orc.lib.orc_set_use_libm(0)
     assert abs(a.mean() / b.mean() - 1.0) < 0.02
+
+
+def test_powf_v1_is_the_correctly_rounded_power_almost_everywhere(orc):
+    """trt-math v1 powf (rt_oracle.c m_powf, f64 inside, one rounding to f32) against numpy's f64 power rounded to f32:
+    identical on this sample (the f64 result carries ~1e-14 relative error, so about one input in 10^6 may round the other
+    way), and C99's special cases.  The reference's libm powf (image.rs:94-96) is pinned by none of its tests."""
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.random(20000).astype(np.float32) * 2, np.exp(rng.uniform(-80, 80, 20000)).astype(np.float32),
+                        np.array([1e-45, 1e-40, 1.1754944e-38, 3.4028235e38], np.float32)])
+    y = np.concatenate([np.full(20000, np.float32(1.0) / np.float32(2.2), np.float32), rng.uniform(-3, 3, 20000).astype(np.float32),
+                        np.array([0.5, 0.45454547, 2.0, 0.25], np.float32)])
+    got = np.array([orc.lib.orc_powf(float(a), float(b)) for a, b in zip(x, y)], np.float32)
+    with np.errstate(all="ignore"):
+        want = np.power(x.astype(np.float64), y.astype(np.float64)).astype(np.float32)
+    ulp = np.abs(got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64))
+    assert ulp.max() <= 1 and (ulp != 0).mean() < 1e-4
+    inf, nan = float("inf"), float("nan")
+    f = orc.lib.orc_powf
+    assert f(nan, 0.0) == 1.0 and f(1.0, nan) == 1.0 and f(5.0, 0.0) == 1.0 and f(-0.0, -0.0) == 1.0
+    assert math.isnan(f(nan, 2.0)) and math.isnan(f(2.0, nan)) and math.isnan(f(-2.0, 0.5))
+    assert f(0.0, 0.5) == 0.0 and f(-0.0, 0.5) == 0.0 and f(0.0, -1.0) == inf and f(-0.0, -1.0) == -inf and f(-0.0, -2.0) == inf
+    assert f(inf, 0.5) == inf and f(inf, -0.5) == 0.0 and f(-inf, 3.0) == -inf and f(-inf, 2.0) == inf and f(-inf, 0.5) == inf
+    assert f(-2.0, 3.0) == -8.0 and f(-2.0, 2.0) == 4.0 and f(2.0, 10.0) == 1024.0 and f(-1.0, inf) == 1.0
+    assert f(0.5, inf) == 0.0 and f(0.5, -inf) == inf and f(2.0, inf) == inf and f(2.0, -inf) == 0.0
+    assert f(3.0, 1.0) == 3.0 and f(2.0, 200.0) == inf and f(2.0, -200.0) == 0.0 and f(4.0, 0.5) == 2.0
+    # libm mode for comparison: at most 1 ulp apart from glibc's powf
+    orc.lib.orc_set_use_libm(1)
+    try:
+        libm = np.array([orc.lib.orc_powf(float(a), float(b)) for a, b in zip(x[:5000], y[:5000])], np.float32)
+    finally:
+        orc.lib.orc_set_use_libm(0)
+    assert np.abs(libm.view(np.int32).astype(np.int64) - got[:5000].view(np.int32).astype(np.int64)).max() <= 1

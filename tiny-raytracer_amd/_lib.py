@@ -93,6 +93,13 @@ SIGNATURES = {
     "trt_camera_init": (C.c_int, [C.POINTER(CameraPOD), C.c_float, C.c_float, Vec3, Vec3, Vec3, C.c_float,
                                   C.c_uint32, C.c_uint32]),
     "trt_render": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.c_void_p, C.POINTER(Stats)]),
+    "trt_render_multi": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.POINTER(C.c_int), C.c_uint32,
+                                   C.c_void_p, C.POINTER(Stats)]),
+    "trt_render_multi_device": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.POINTER(C.c_int),
+                                          C.c_uint32, C.c_void_p, C.POINTER(Stats)]),
+    "trt_band_rows_local": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "trt_kernel_timing_begin": (C.c_int, []),
+    "trt_kernel_timing_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "trt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
                                     C.c_void_p]),
     "trt_sample_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, Vec3, C.c_uint32,

@@ -218,6 +218,27 @@ class Renderer:
         self.last_stats = st.as_dict()
         return Image(accum)
 
+    def render_multi(self, camera, world, devices=None, accum=None, d_accum_ptr=None, collect_stats=False, **over):
+        """Renderer::render over several GPUs of one node (trt_render_multi): one call, the whole Image back.  `devices`:
+        list of ordinals (None = all visible).  With d_accum_ptr the frame is gathered into that buffer on devices[0]
+        instead (trt_render_multi_device) and nothing is returned."""
+        scene = world.get_bvh() if isinstance(world, World) else world
+        p = self.params(collect_stats=int(collect_stats), **over)
+        w, h = camera.get_image_size()
+        ndev = len(devices) if devices is not None else 0
+        dv = (C.c_int * ndev)(*devices) if ndev else None
+        st = Stats()
+        if d_accum_ptr is not None:
+            check(lib.trt_render_multi_device(scene._h, C.byref(camera.pod), C.byref(p), dv, ndev, C.c_void_p(d_accum_ptr), C.byref(st)))
+            self.last_stats = st.as_dict()
+            return None
+        if accum is None:
+            accum = np.zeros((h, w, 3), np.float32)
+        assert accum.dtype == np.float32 and accum.flags.c_contiguous and accum.shape == (h, w, 3)
+        check(lib.trt_render_multi(scene._h, C.byref(camera.pod), C.byref(p), dv, ndev, accum.ctypes.data, C.byref(st)))
+        self.last_stats = st.as_dict()
+        return Image(accum)
+
     def render_device(self, camera, scene, d_accum_ptr, stream_ptr=0, d_counters_ptr=0, **over):
         """Enqueue one pass on buffers already in HBM (device pointers as integers); asynchronous."""
         p = self.params(**over)

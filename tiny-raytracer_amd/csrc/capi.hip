@@ -11,10 +11,13 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
+#include <vector>
 
 #include "kernels.h"
 #include "scene.h"
@@ -25,12 +28,44 @@ struct trt_world {
     World w;
 };
 
+// trt_kernel_timing_begin / _end: HIP events around every dominant-kernel launch, process-wide
+namespace trt {
+namespace {
+std::mutex g_timing_mu;
+bool g_timing_on = false;
+std::vector<hipEvent_t> g_timing_events;        // begin, end, begin, end, ...
+}  // namespace
+void timing_mark(hipStream_t stream, bool begin) {
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    if (!g_timing_on) return;
+    if (begin != (g_timing_events.size() % 2 == 0)) return;       // concurrent renders interleaved their marks: keep pairs intact
+    hipEvent_t ev = nullptr;
+    if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventRecord(ev, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); return; }
+    g_timing_events.push_back(ev);
+}
+}  // namespace trt
+
+// Device scratch of one render (wavefront: path-state planes; streamed: the radiance records of a chunk + the batch
+// counter).  Renders of one scene may run concurrently - from several host threads, on several streams - so a render
+// never shares a workspace with another one that may still be running: each takes one from a per-(scene, device) pool
+// and gives it back with an event recorded behind its last kernel; a workspace is handed out again only to a stream that
+// first waits for that event (stream-ordered reuse), and the pool prefers workspaces whose event has already fired.
+struct Workspace {
+    void* ptr = nullptr;
+    size_t bytes = 0;
+    hipEvent_t done = nullptr;      // recorded behind the last kernel that used the workspace
+    bool recorded = false;
+    bool busy = false;              // a host thread is between acquire and release (its launches are not all enqueued yet)
+};
+constexpr size_t kMaxWorkspacesPerDevice = 8;      // beyond that, renders queue behind each other on the device
+
 struct trt_scene {
     SceneHost host;
     std::mutex mu;
+    std::condition_variable cv;
     std::unordered_map<int, float4*> device_blob;     // device ordinal -> packed scene in HBM
-    struct Workspace { void* ptr = nullptr; size_t bytes = 0; };
-    std::unordered_map<int, Workspace> wavefront_ws;  // device ordinal -> wavefront path-state planes (grown on demand)
+    std::unordered_map<int, std::vector<Workspace*>> ws_pool;   // device ordinal -> workspaces (grown on demand)
 };
 
 namespace {
@@ -77,6 +112,80 @@ int scene_on_device(trt_scene* s, SceneDev& out) {
     }
     out.blob = d;
     out.L = s->host.layout;
+    return TRT_OK;
+}
+
+// Takes a workspace of at least `need` bytes for a render that will be enqueued on `stream` of device `dev`.
+int workspace_acquire(trt_scene* s, int dev, size_t need, hipStream_t stream, Workspace** out) {
+    std::unique_lock<std::mutex> lock(s->mu);
+    std::vector<Workspace*>& pool = s->ws_pool[dev];
+    for (;;) {
+        Workspace* pick = nullptr;
+        // 1. an idle one whose last render has finished (no dependency at all); the smallest that fits, else any to regrow
+        Workspace* finished_small = nullptr;
+        for (Workspace* w : pool) {
+            if (w->busy) continue;
+            const bool finished = !w->recorded || hipEventQuery(w->done) == hipSuccess;
+            if (!finished) continue;
+            if (w->bytes >= need) { if (!pick || w->bytes < pick->bytes) pick = w; }
+            else if (!finished_small) finished_small = w;
+        }
+        (void)hipGetLastError();                              // hipEventQuery's hipErrorNotReady is not an error
+        if (!pick && finished_small) {                        // grow a finished one in place
+            Workspace* w = finished_small;
+            if (w->ptr) { hipError_t e = hipFree(w->ptr); w->ptr = nullptr; w->bytes = 0; if (e != hipSuccess) return fail_hip(e, "hipFree(workspace)"); }
+            hipError_t e = hipMalloc(&w->ptr, need);
+            if (e != hipSuccess) { w->ptr = nullptr; return fail_hip(e, "hipMalloc(workspace)"); }
+            w->bytes = need;
+            w->recorded = false;
+            pick = w;
+        }
+        // 2. a new one while the pool may grow
+        if (!pick && pool.size() < kMaxWorkspacesPerDevice) {
+            Workspace* w = new (std::nothrow) Workspace();
+            if (!w) return fail(TRT_ERR_OOM, "out of memory");
+            hipError_t e = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipMalloc(&w->ptr, need);
+            if (e != hipSuccess) {
+                if (w->done) (void)hipEventDestroy(w->done);
+                delete w;
+                if (pool.empty()) return fail_hip(e, "hipMalloc(workspace)");
+                (void)hipGetLastError();                      // out of HBM for another copy: queue behind a running render instead
+            } else {
+                w->bytes = need;
+                pool.push_back(w);
+                pick = w;
+            }
+        }
+        // 3. an idle one that is still in flight and large enough: this render queues behind it on the device
+        if (!pick) {
+            for (Workspace* w : pool) if (!w->busy && w->bytes >= need) { pick = w; break; }
+        }
+        if (pick) {
+            if (pick->recorded) TRT_HIP(hipStreamWaitEvent(stream, pick->done, 0));
+            pick->busy = true;
+            *out = pick;
+            return TRT_OK;
+        }
+        // 4. every workspace is being enqueued on by another host thread, or is in flight and too small: wait for a release
+        bool any_busy = false;
+        for (Workspace* w : pool) any_busy = any_busy || w->busy;
+        if (any_busy) { s->cv.wait(lock); continue; }
+        // all idle, all in flight, all too small: wait for the first to finish, then regrow it
+        TRT_HIP(hipEventSynchronize(pool.front()->done));
+    }
+}
+
+// Gives the workspace back; `stream` has all of the render's launches enqueued.
+int workspace_release(trt_scene* s, Workspace* w, hipStream_t stream) {
+    const hipError_t e = hipEventRecord(w->done, stream);
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        w->recorded = (e == hipSuccess);
+        w->busy = false;
+    }
+    s->cv.notify_all();
+    if (e != hipSuccess) return fail_hip(e, "hipEventRecord(workspace)");
     return TRT_OK;
 }
 
@@ -146,32 +255,26 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
     const bool wavefront = p->backend == TRT_BACKEND_WAVEFRONT;
     const bool streamed = p->backend == TRT_BACKEND_STREAMED || p->backend == TRT_BACKEND_AUTO;     // fastest on every scene measured
     if (wavefront || streamed) {
-        // Device workspace (wavefront: 72 B of path state per pixel; streamed: 12 B per pixel and sample of a 64-spp chunk),
-        // cached on the scene handle per device and grown on demand.  One such render at a time per scene handle and
-        // device (the workspace is shared); the megakernel has no such restriction.
+        // Device workspace (wavefront: 72 B of path state per pixel; streamed: 12 B per pixel and sample of a chunk), private
+        // to this render until its last kernel has run (workspace_acquire): concurrent renders of one scene are safe.
         int dev = 0;
         TRT_HIP(hipGetDevice(&dev));
         const size_t need = wavefront ? wavefront_workspace_bytes(cam->width, rows) : streamed_workspace_bytes(cam->width, rows);
-        void* ws = nullptr;
-        {
-            std::lock_guard<std::mutex> lock(s->mu);
-            trt_scene::Workspace& w = s->wavefront_ws[dev];
-            if (w.bytes < need) {
-                if (w.ptr) { TRT_HIP(hipStreamSynchronize(stream)); TRT_HIP(hipFree(w.ptr)); w.ptr = nullptr; w.bytes = 0; }
-                TRT_HIP(hipMalloc(&w.ptr, need));
-                w.bytes = need;
-            }
-            ws = w.ptr;
-        }
+        Workspace* ws = nullptr;
+        rc = workspace_acquire(s, dev, need, stream, &ws);
+        if (rc != TRT_OK) return rc;
+        hipError_t le;
         if (streamed) {
-            TRT_HIP(launch_streamed(sc, cd, ra, ws, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));
-            return TRT_OK;
+            le = launch_streamed(sc, cd, ra, ws->ptr, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream);
+        } else {
+            uint32_t serve_min = 0;
+            if (const char* e = getenv("TRT_WF_SERVE_MIN")) serve_min = (uint32_t)atoi(e);
+            le = launch_wavefront(sc, cd, ra, ws->ptr, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0,
+                                  serve_min, stream);
         }
-        uint32_t serve_min = 0;
-        if (const char* e = getenv("TRT_WF_SERVE_MIN")) serve_min = (uint32_t)atoi(e);
-        TRT_HIP(launch_wavefront(sc, cd, ra, ws, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0,
-                                 serve_min, stream));
-        return TRT_OK;
+        rc = workspace_release(s, ws, stream);
+        if (le != hipSuccess) return fail_hip(le, streamed ? "launch_streamed" : "launch_wavefront");
+        return rc;
     }
     TRT_HIP(launch_megakernel(sc, cd, ra, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));
     return TRT_OK;
@@ -272,15 +375,22 @@ int trt_scene_create(const trt_world* w, trt_scene** out) {
 }
 void trt_scene_destroy(trt_scene* s) {
     if (!s) return;
-    for (auto& kv : s->device_blob) {
-        int prev = 0;
-        if (hipGetDevice(&prev) == hipSuccess && hipSetDevice(kv.first) == hipSuccess) {
-            (void)hipFree(kv.second);
-            auto ws = s->wavefront_ws.find(kv.first);
-            if (ws != s->wavefront_ws.end() && ws->second.ptr) (void)hipFree(ws->second.ptr);
-            (void)hipSetDevice(prev);
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (auto& kv : s->ws_pool) {
+        if (hipSetDevice(kv.first) != hipSuccess) continue;
+        for (Workspace* w : kv.second) {
+            if (w->recorded) (void)hipEventSynchronize(w->done);      // a render may still be using it
+            if (w->ptr) (void)hipFree(w->ptr);
+            if (w->done) (void)hipEventDestroy(w->done);
+            delete w;
         }
     }
+    for (auto& kv : s->device_blob) {
+        if (hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second);
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
     delete s;
 }
 int trt_scene_get_info(const trt_scene* s, trt_scene_info* out) {
@@ -383,6 +493,192 @@ int trt_render(trt_scene* s, const trt_camera* cam, const trt_render_params* p, 
     return TRT_OK;
 }
 
+// ---- Renderer::render over several GPUs of one node ----
+//
+// renderer.rs:37-79 is ONE call that returns the whole Image; so is this.  The path shards by pixels (every sample reads
+// only the immutable scene, cpu.rs:39-65): the scene is replicated, the image is cut into bands of kMultiBandRows rows dealt
+// round-robin (band b -> device b % ndev, so expensive regions spread over all devices), the RNG is keyed by the image
+// pixel, and every device folds its own pixels in sample order - the frame is bit-identical for every ndev.  One host
+// thread per device enqueues that device's bands on a stream of its own; the only exchange is the gather of the
+// finished f32 sums: each band goes straight to its place in the destination frame (a host buffer: one D2H copy per
+// band; a buffer on devices[0]: one peer copy over xGMI per band), so no un-interleave pass exists.
+namespace {
+
+constexpr uint32_t kMultiBandRows = 16;
+
+struct MultiShard {
+    int device = 0;
+    uint32_t rank = 0, rows_local = 0;
+    int rc = TRT_OK;
+    std::string error;
+    unsigned long long ctr[CTR_COUNT] = {0};
+    float ms = 0.0f;
+};
+
+uint32_t band_rows_local(uint32_t height, uint32_t ndev, uint32_t rank, uint32_t band_rows) {
+    const uint32_t n_bands = (height + band_rows - 1u) / band_rows;
+    uint32_t rows = 0;
+    for (uint32_t b = rank; b < n_bands; b += ndev) rows += (b + 1u) * band_rows <= height ? band_rows : height - b * band_rows;
+    return rows;
+}
+
+// One device's share.  dst: the whole frame, on the host (dst_device < 0) or on device dst_device.
+void render_shard(trt_scene* s, const trt_camera* cam, const trt_render_params* p, uint32_t ndev, MultiShard* sh, float* dst,
+                  int dst_device) {
+    float* d_accum = nullptr;
+    unsigned long long* d_ctr = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    auto cleanup = [&]() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+        if (d_accum) (void)hipFree(d_accum);
+        if (d_ctr) (void)hipFree(d_ctr);
+    };
+#define TRT_HIP_S(call)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e_ = (call);                                                                                 \
+        if (e_ != hipSuccess) { sh->rc = fail_hip(e_, #call); sh->error = g_last_error; cleanup(); return; }    \
+    } while (0)
+    TRT_HIP_S(hipSetDevice(sh->device));
+    if (sh->rows_local == 0) return;                                        // more devices than bands
+    const size_t row_bytes = (size_t)cam->width * 3 * sizeof(float);
+    trt_render_params q = *p;
+    q.band_rows = kMultiBandRows; q.band_stride = ndev; q.band_offset = sh->rank; q.rows_local = sh->rows_local;
+    TRT_HIP_S(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    TRT_HIP_S(hipEventCreate(&ev0));
+    TRT_HIP_S(hipEventCreate(&ev1));
+    TRT_HIP_S(hipMalloc(reinterpret_cast<void**>(&d_accum), row_bytes * sh->rows_local));
+    TRT_HIP_S(hipMalloc(reinterpret_cast<void**>(&d_ctr), sizeof(sh->ctr)));
+    TRT_HIP_S(hipMemsetAsync(d_ctr, 0, sizeof(sh->ctr), stream));
+    // local rows [r0, r0 + n) = image rows [y0, y0 + n): one contiguous band
+    auto for_each_band = [&](auto&& fn) -> hipError_t {
+        uint32_t r0 = 0;
+        for (uint32_t b = sh->rank; r0 < sh->rows_local; b += ndev) {
+            const uint32_t y0 = b * kMultiBandRows;
+            const uint32_t n = y0 + kMultiBandRows <= cam->height ? kMultiBandRows : cam->height - y0;
+            hipError_t e = fn(r0, y0, n);
+            if (e != hipSuccess) return e;
+            r0 += n;
+        }
+        return hipSuccess;
+    };
+    if (p->accumulate) {                                                    // continue the running sums of the frame
+        TRT_HIP_S(for_each_band([&](uint32_t r0, uint32_t y0, uint32_t n) {
+            float* local = d_accum + (size_t)r0 * cam->width * 3;
+            const float* frame = dst + (size_t)y0 * cam->width * 3;
+            return dst_device < 0 ? hipMemcpyAsync(local, frame, row_bytes * n, hipMemcpyHostToDevice, stream)
+                                  : hipMemcpyPeerAsync(local, sh->device, frame, dst_device, row_bytes * n, stream);
+        }));
+    }
+    TRT_HIP_S(hipEventRecord(ev0, stream));
+    sh->rc = enqueue_render(s, cam, &q, d_accum, reinterpret_cast<uint64_t*>(d_ctr), stream, nullptr);
+    if (sh->rc != TRT_OK) { sh->error = g_last_error; (void)hipStreamSynchronize(stream); cleanup(); return; }
+    TRT_HIP_S(hipEventRecord(ev1, stream));
+    TRT_HIP_S(for_each_band([&](uint32_t r0, uint32_t y0, uint32_t n) {     // the gather: every band to its place in the frame
+        const float* local = d_accum + (size_t)r0 * cam->width * 3;
+        float* frame = dst + (size_t)y0 * cam->width * 3;
+        return dst_device < 0 ? hipMemcpyAsync(frame, local, row_bytes * n, hipMemcpyDeviceToHost, stream)
+                              : hipMemcpyPeerAsync(frame, dst_device, local, sh->device, row_bytes * n, stream);
+    }));
+    TRT_HIP_S(hipMemcpyAsync(sh->ctr, d_ctr, sizeof(sh->ctr), hipMemcpyDeviceToHost, stream));
+    TRT_HIP_S(hipStreamSynchronize(stream));
+    TRT_HIP_S(hipEventElapsedTime(&sh->ms, ev0, ev1));
+    cleanup();
+#undef TRT_HIP_S
+}
+
+int render_multi(trt_scene* s, const trt_camera* cam, const trt_render_params* p, const int* devices, uint32_t ndev, float* dst,
+                 bool dst_on_device, trt_stats* stats) {
+    if (!s || !cam || !p || !dst) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    int rc = require_device();
+    if (rc != TRT_OK) return rc;
+    if (p->band_rows != 0) return fail(TRT_ERR_INVALID_ARG, "trt_render_multi lays out the bands itself: band_rows must be 0");
+    const int visible = trt_device_count();
+    if (ndev == 0) ndev = (uint32_t)visible;
+    if (ndev > 64) return fail(TRT_ERR_INVALID_ARG, "at most 64 shards");
+    std::vector<MultiShard> shards(ndev);
+    for (uint32_t r = 0; r < ndev; r++) {
+        const int d = devices ? devices[r] : (int)r;
+        if (d < 0 || d >= visible) return fail(TRT_ERR_INVALID_ARG, "device ordinal out of range");
+        shards[r].device = d;
+        shards[r].rank = r;
+        shards[r].rows_local = band_rows_local(cam->height, ndev, r, kMultiBandRows);
+    }
+    {   // validate once on the calling thread, so argument errors do not depend on a device
+        RenderArgs probe;
+        uint32_t rows = 0;
+        rc = to_render_args(cam, p, probe, rows);
+        if (rc != TRT_OK) return rc;
+    }
+    int prev = 0;
+    TRT_HIP(hipGetDevice(&prev));
+    const int dst_device = dst_on_device ? shards[0].device : -1;
+    if (dst_on_device) {
+        for (uint32_t r = 1; r < ndev; r++) {                               // peer access for the gather (xGMI)
+            if (shards[r].device == dst_device) continue;
+            int can = 0;
+            TRT_HIP(hipDeviceCanAccessPeer(&can, shards[r].device, dst_device));
+            if (!can) continue;                                             // hipMemcpyPeerAsync then stages through the host
+            TRT_HIP(hipSetDevice(shards[r].device));
+            hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipSetDevice(prev); return fail_hip(e, "hipDeviceEnablePeerAccess"); }
+            (void)hipGetLastError();
+        }
+        TRT_HIP(hipSetDevice(prev));
+    }
+    if (ndev == 1) {
+        render_shard(s, cam, p, 1, &shards[0], dst, dst_device);
+    } else {
+        std::vector<std::thread> workers;
+        try {
+            for (uint32_t r = 0; r < ndev; r++) workers.emplace_back(render_shard, s, cam, p, ndev, &shards[r], dst, dst_device);
+        } catch (...) {
+            for (auto& t : workers) t.join();
+            (void)hipSetDevice(prev);
+            return fail(TRT_ERR_OOM, "could not start a host thread per device");
+        }
+        for (auto& t : workers) t.join();
+    }
+    (void)hipSetDevice(prev);
+    unsigned long long total[CTR_COUNT] = {0};
+    float ms = 0.0f;
+    for (const MultiShard& sh : shards) {
+        if (sh.rc != TRT_OK) return fail(sh.rc, "device " + std::to_string(sh.device) + ": " + sh.error);
+        for (int k = 0; k < CTR_COUNT; k++) total[k] += sh.ctr[k];
+        if (sh.ms > ms) ms = sh.ms;
+    }
+    if (stats) { counters_to_stats(total, stats); stats->kernel_ms = ms; }      // kernel_ms: the slowest device's
+    return TRT_OK;
+}
+
+}  // namespace
+
+int trt_render_multi(trt_scene* s, const trt_camera* cam, const trt_render_params* p, const int* devices, uint32_t ndev, float* accum,
+                     trt_stats* stats) {
+    try {
+        return render_multi(s, cam, p, devices, ndev, accum, false, stats);
+    } catch (const std::bad_alloc&) {
+        return fail(TRT_ERR_OOM, "out of memory");
+    }
+}
+
+int trt_render_multi_device(trt_scene* s, const trt_camera* cam, const trt_render_params* p, const int* devices, uint32_t ndev,
+                            float* d_accum, trt_stats* stats) {
+    try {
+        return render_multi(s, cam, p, devices, ndev, d_accum, true, stats);
+    } catch (const std::bad_alloc&) {
+        return fail(TRT_ERR_OOM, "out of memory");
+    }
+}
+
+int trt_band_rows_local(uint32_t height, uint32_t ndev, uint32_t rank, uint32_t* rows_local) {
+    if (!rows_local || ndev == 0 || rank >= ndev) return fail(TRT_ERR_INVALID_ARG, "need 0 <= rank < ndev and a result pointer");
+    *rows_local = band_rows_local(height, ndev, rank, kMultiBandRows);
+    return TRT_OK;
+}
+
 // ---- Sampler::sampling, batch form ----
 int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_sampled_color* out, uint32_t max_bounces,
                      trt_vec3 background, uint32_t seed, trt_stats* stats) {
@@ -439,6 +735,35 @@ int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_s
 }
 
 uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows) { return streamed_chunk_spp(width, rows); }
+
+int trt_kernel_timing_begin(void) {
+    std::lock_guard<std::mutex> lock(trt::g_timing_mu);
+    for (hipEvent_t ev : trt::g_timing_events) (void)hipEventDestroy(ev);
+    trt::g_timing_events.clear();
+    trt::g_timing_on = true;
+    return TRT_OK;
+}
+int trt_kernel_timing_end(double* total_ms, uint32_t* launches) {
+    std::lock_guard<std::mutex> lock(trt::g_timing_mu);
+    trt::g_timing_on = false;
+    double sum = 0.0;
+    uint32_t n = 0;
+    int rc = TRT_OK;
+    std::vector<hipEvent_t>& evs = trt::g_timing_events;
+    for (size_t k = 0; k + 1 < evs.size(); k += 2) {
+        float ms = 0.0f;
+        hipError_t e = hipEventSynchronize(evs[k + 1]);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, evs[k], evs[k + 1]);
+        if (e != hipSuccess) { rc = fail_hip(e, "kernel timing events"); break; }
+        sum += ms;
+        n++;
+    }
+    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
+    evs.clear();
+    if (total_ms) *total_ms = sum;
+    if (launches) *launches = n;
+    return rc;
+}
 
 // Name of the kernel that dominates a render with these settings (what a profile of it shows).
 const char* trt_dominant_kernel(const trt_scene* s, const trt_camera* cam, const trt_render_params* p) {

@@ -50,6 +50,11 @@ enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD
 inline int scene_mode(const SceneLayout& L) { return L.hot_bytes <= kLdsSceneMaxBytes ? 1 : (L.n_top_nodes > 0 ? 2 : 0); }
 inline uint32_t scene_lds_bytes(const SceneLayout& L) { int m = scene_mode(L); return m == 1 ? L.hot_bytes : (m == 2 ? 32u * L.n_top_nodes : 0u); }
 
+// Optional device timing of the dominant kernel (trt_kernel_timing_begin / _end, capi.hip): while enabled, a launcher
+// brackets every launch of its dominant kernel with timing_mark(stream, true) / timing_mark(stream, false), which record
+// HIP events on the launch stream.  No-ops while disabled.
+void timing_mark(hipStream_t stream, bool begin);
+
 // Megakernel: whole bounce loop for every pixel of the local rows in one launch.
 hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
                              unsigned long long* d_counters, bool stats, hipStream_t stream);

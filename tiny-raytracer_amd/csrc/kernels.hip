@@ -147,8 +147,11 @@ static hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    timing_mark(stream, true);
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
-    return hipGetLastError();
+    const hipError_t le = hipGetLastError();
+    timing_mark(stream, false);
+    return le;
 }
 
 hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,

@@ -114,7 +114,5 @@ void camera_init(trt_camera& out, float focus_distance, float defocus_angle_deg,
 
 // Image finalisation (imager.rs:52-53; utils/image.rs:92-111)
 void tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* rgb);
-// trt-math v1 powf (trt_pow.h), exported for tests
-float powf_v1(float x, float y);
 
 }  // namespace trt

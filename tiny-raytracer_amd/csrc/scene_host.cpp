@@ -586,6 +586,4 @@ void tonemap_u8(const float* accum, uint32_t npixels, float gamma, uint8_t* rgb)
     for (size_t i = 0; i < (size_t)npixels * 3; i++) rgb[i] = tm_quantise_channel(accum[i], inv_gamma);
 }
 
-float powf_v1(float x, float y) { return tm_powf(x, y); }
-
 }  // namespace trt

@@ -390,8 +390,11 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                 hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
                 if (e2 != hipSuccess) return e2;
             }
+            timing_mark(stream, true);
             hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches, batch_spp, leaf_list, nodes16, ordered16);
-            return hipGetLastError();
+            const hipError_t le = hipGetLastError();
+            timing_mark(stream, false);
+            return le;
         };
         switch (mode) {
             case MODE_LDS:

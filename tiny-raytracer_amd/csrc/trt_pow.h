@@ -3,7 +3,7 @@
 //
 // The reference calls the platform libm through Rust's std, which no test of the reference pins and which the GPU
 // does not have; like sin/cos/acos/cbrt (rt_device.h) this project fixes ONE algorithm and uses it everywhere - host
-// tonemap (scene_host.cpp), device tonemap (kernels.hip) and, restated in C, the CPU oracle (oracle/rt_oracle.c
+// tonemap (scene_host.cpp), device tonemap (kernels.hip) and, restated in C, the test suite's CPU checker (its
 // m_powf) - so the three produce the same float for every input and the quantised frames are compared byte for byte.
 //
 // Algorithm: x^y = 2^k * exp(r), y * log(x) = k ln2 + r, evaluated in f64 with + - * / and bit moves only (each

@@ -297,8 +297,11 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
             if (e != hipSuccess) return e;
         }
+        timing_mark(stream, true);
         hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, st, d_accum, d_counters, tiles_x, serve_min);
-        return hipGetLastError();
+        const hipError_t le = hipGetLastError();
+        timing_mark(stream, false);
+        return le;
     };
     switch (scene_mode(sc.L)) {
         case MODE_LDS: return stats ? go(wavefront_kernel<MODE_LDS, true>) : go(wavefront_kernel<MODE_LDS, false>);
