@@ -278,23 +278,40 @@ TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
 // with every inner node pruned, so the argument of walk_fast applies unchanged: leaves whose box passes are put
 // aside with their `start` and tested in walk order, each only if its box still passes with the current t_best.
 // All lanes that call this must enter together (they do: a wave's lanes start their walks in the same trip).
+// The loop is software-pipelined by hand: a trip tests TWO leaves, and the scalar loads of the next trip's pair are
+// issued before this trip's boxes are tested (the compiler otherwise waits for each node right after requesting it,
+// `s_load_dwordx4; s_waitcnt lgkmcnt(0)`, once per box step, and spends 3 branches and ~10 scalar instructions per step).
 template <int MODE, bool STATS>
 TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf_list, const Ray& ray, Trav& tr, Counters<STATS>& ctr,
                        float2* stk, uint32_t slots) {
-    const uint32_t n = sc.L.n_leaves;
+    const uint32_t n = sc.L.n_leaves;                    // >= 1
+    const uint32_t last = n - 1u;
     uint32_t i = 0;                                      // wave-uniform
+    float4 a0 = leaf_list[0], b0 = leaf_list[1];
+    const uint32_t i1 = last < 1u ? last : 1u;
+    float4 a1 = leaf_list[2u * i1], b1 = leaf_list[2u * i1 + 1u];
     do {
         uint32_t cnt = 0;
         for (; i < n;) {
-            const float4 na = leaf_list[2u * i], nb = leaf_list[2u * i + 1u];
-            i++;
+            // request the next pair (indices clamped to the list: a harmless re-read at the end)
+            const uint32_t j0 = i + 2u < last ? i + 2u : last, j1 = i + 3u < last ? i + 3u : last;
+            const float4 na0 = leaf_list[2u * j0], nb0 = leaf_list[2u * j0 + 1u], na1 = leaf_list[2u * j1], nb1 = leaf_list[2u * j1 + 1u];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
             float start;
-            if (slab_fast_entry(na, nb, ray.o, tr.inv, kTMin, tr.t_best, start)) {
-                stk[64u * cnt] = make_float2(nb.w, start);
+            if (slab_fast_entry(a0, b0, ray.o, tr.inv, kTMin, tr.t_best, start)) {
+                stk[64u * cnt] = make_float2(b0.w, start);
                 cnt++;
             }
-            if (__builtin_amdgcn_ballot_w64(cnt >= slots) != 0ull) break;        // some lane's slots are full: test what is pending
+            if (i + 1u < n) {
+                if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
+                if (slab_fast_entry(a1, b1, ray.o, tr.inv, kTMin, tr.t_best, start)) {
+                    stk[64u * cnt] = make_float2(b1.w, start);
+                    cnt++;
+                }
+            }
+            i += 2u;
+            a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
+            if (__builtin_amdgcn_ballot_w64(cnt + 2u > slots) != 0ull) break;    // some lane could not hold another pair: test what is pending
         }
         for (uint32_t k = 0; k < cnt; k++) {
             const float2 e = stk[64u * k];
@@ -476,27 +493,49 @@ TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
 
 constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)
 
+// Which walk a kernel instantiation runs.  WALK_RUNTIME picks by the launch arguments (every knob combination; counting
+// kernels); the others fix the walk at compile time, which is what the production launches use: the kernel then holds ONE
+// walk instead of five, with the SGPRs, VGPRs and instruction-cache footprint of one (stream_pool_kernel on Cornell:
+// 6849 lines of ISA, 44 spilled SGPRs and 16 spilled VGPRs with the runtime choice).
+enum { WALK_RUNTIME = 0, WALK_LDS_STACK = 1, WALK_FLAT = 2, WALK_COMPACT = 3, WALK_ORDERED = 4, WALK_REGS = 5 };
+
 // Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  Postponed leaves go to
 // `lds_stack` (this lane's slot 0 of a `leaf_slots`-deep LDS stack) if the kernel has one, else into registers:
 // `leaf_slots` = 4 (also for 0 = default), 2 or 1 (tuning and tests; wave-uniform).
-template <int MODE, bool STATS>
+template <int MODE, bool STATS, int WALK = WALK_RUNTIME>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
                              uint32_t leaf_slots = 4u, float2* lds_stack = nullptr, const float4* __restrict__ leaf_list = nullptr,
                              const uint4* __restrict__ nodes16 = nullptr, const uint4* __restrict__ ordered16 = nullptr) {
     Trav tr = trav_begin(sc, ray, ref_tree);
     if (__builtin_expect(!tr.ref, 1)) {
-        if (lds_stack != nullptr && ordered16 != nullptr) {
+        if constexpr (WALK == WALK_ORDERED) {
             const uint32_t octant = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
             if (!walk_ordered<MODE, STATS>(sc, ordered16 + (size_t)octant * sc.L.n_ordered_nodes, leaf_list, ray, tr, ctr, lds_stack, leaf_slots)) {
                 tr = trav_begin(sc, ray, ref_tree);                                     // unsafe winner: the fixed-order walk decides
                 walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
             }
-        } else if (lds_stack != nullptr && nodes16 != nullptr) walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
-        else if (lds_stack != nullptr && leaf_list != nullptr) walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
-        else if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
-        else if (leaf_slots >= 4u || leaf_slots == 0u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
-        else if (leaf_slots >= 2u) walk_fast<MODE, STATS, 2>(sc, ray, tr, ctr);
-        else walk_fast<MODE, STATS, 1>(sc, ray, tr, ctr);
+        } else if constexpr (WALK == WALK_COMPACT) {
+            walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+        } else if constexpr (WALK == WALK_FLAT) {
+            walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+        } else if constexpr (WALK == WALK_LDS_STACK) {
+            walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
+        } else if constexpr (WALK == WALK_REGS) {
+            walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
+        } else {
+            if (lds_stack != nullptr && ordered16 != nullptr) {
+                const uint32_t octant = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
+                if (!walk_ordered<MODE, STATS>(sc, ordered16 + (size_t)octant * sc.L.n_ordered_nodes, leaf_list, ray, tr, ctr, lds_stack, leaf_slots)) {
+                    tr = trav_begin(sc, ray, ref_tree);                                 // unsafe winner: the fixed-order walk decides
+                    walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+                }
+            } else if (lds_stack != nullptr && nodes16 != nullptr) walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+            else if (lds_stack != nullptr && leaf_list != nullptr) walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+            else if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
+            else if (leaf_slots >= 4u || leaf_slots == 0u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
+            else if (leaf_slots >= 2u) walk_fast<MODE, STATS, 2>(sc, ray, tr, ctr);
+            else walk_fast<MODE, STATS, 1>(sc, ray, tr, ctr);
+        }
     } else {
         closest_hit_ref<MODE, STATS>(sc, ray, tr, ctr);
     }

@@ -33,7 +33,7 @@ TRT_DEV uint32_t st_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <int MODE, bool STATS, int MINW = 1, int THREADS = 256>
+template <int MODE, bool STATS, int MINW = 1, int THREADS = 256, int WALK = WALK_RUNTIME>
 __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev scd, CameraDev cam, RenderArgs ra,
                                                                              float* __restrict__ colors,
                                                                              uint32_t* __restrict__ batch_counter,
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     const uint32_t n_spp = ra.sample_end - ra.sample_begin;
     const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
     // postponed-leaf stack (rt_path.h walk_fast_lds): behind the scene copy, leaf_slots x 64 x 8 bytes per wave
-    float2* const leaf_stack = ra.lds_leaf_stack
+    float2* const leaf_stack = (WALK != WALK_REGS && (WALK != WALK_RUNTIME || ra.lds_leaf_stack))
         ? reinterpret_cast<float2*>(reinterpret_cast<char*>(g_lds) + ((sc.lds_bytes() + 15u) & ~15u)) + (threadIdx.x >> 6) * (64u * ra.leaf_slots) + lane
         : nullptr;
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
+            const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
 // ------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kPoolDwords = 9u;         // origin, direction, rng state, radiance slot
 
-template <int MODE, bool STATS, int MINW = 1, int THREADS = 256>
+template <int MODE, bool STATS, int MINW = 1, int THREADS = 256, int WALK = WALK_RUNTIME>
 __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd, CameraDev cam, RenderArgs ra,
                                                                            float* __restrict__ colors,
                                                                            uint32_t* __restrict__ batch_counter,
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
             float t;
-            const uint32_t prim = closest_hit<MODE, STATS>(sc, p.ray, ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
+            const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
             if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -309,10 +309,11 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
     if (w < 5) w = 5;
     if (threads == 512 && w > 6) w = 6;
     uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
-    // slots of the LDS stack: 4 for tree walks; 6 for the lock-step leaf list, whose t_best stays stale for a whole walk
-    // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12)
+    // slots of the LDS stack: 4 for tree walks; 7 for the lock-step leaf list, whose t_best stays stale for a whole walk
+    // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12) and which steps two leaves per trip, so a lane must have two free
     const bool flat = L.flat_walk && !ra_all.ref_tree;
-    const uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 6u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
+    uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 7u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
+    if (flat && slots < 2u) slots = 2u;                                         // walk_flat pushes up to two leaves per trip
     const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
     const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
     // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
@@ -396,7 +397,20 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
             timing_mark(stream, false);
             return le;
         };
-        switch (mode) {
+        // production defaults run kernels with the walk fixed at compile time; every other knob combination and the counting
+        // variants run the runtime-dispatch instantiations below
+        const int walk = pl.ordered ? WALK_ORDERED : pl.compact ? WALK_COMPACT : pl.flat ? WALK_FLAT : lds_stack ? WALK_LDS_STACK : WALK_REGS;
+        const bool slots_ok = lds_stack || ra_all.leaf_slots == 0u || ra_all.leaf_slots >= 4u;      // WALK_REGS has 4 register slots
+        bool specialised = !stats && slots_ok && getenv("TRT_RUNTIME_WALK") == nullptr;
+        if (specialised) {
+            if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_FLAT>);
+            else if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_LDS_STACK) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_LDS_STACK>);
+            else if (mode == MODE_LDS && threads == 512 && w == 6 && walk == WALK_REGS) e = go(stream_sample_kernel<MODE_LDS, false, 6, 512, WALK_REGS>);
+            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_COMPACT) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_COMPACT>);
+            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_ORDERED) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_ORDERED>);
+            else specialised = false;
+        }
+        if (!specialised) switch (mode) {
             case MODE_LDS:
                 if (threads == 512) {
                     if (w >= 6) e = launch_pick<MODE_LDS, 6, 512>(stats, go);
