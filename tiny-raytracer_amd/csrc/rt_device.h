@@ -251,6 +251,19 @@ TRT_DEV bool slab_fast6(V3 lo, V3 hi, V3 o, V3 inv, float start, float end) {
     return !(end <= start);
 }
 
+// ... and with the interval's start returned (see slab_fast_entry)
+TRT_DEV bool slab_fast6_entry(V3 lo, V3 hi, V3 o, V3 inv, float start, float end, float& start_out) {
+    float x0 = (lo.x - o.x) * inv.x, x1 = (hi.x - o.x) * inv.x;
+    float y0 = (lo.y - o.y) * inv.y, y1 = (hi.y - o.y) * inv.y;
+    float z0 = (lo.z - o.z) * inv.z, z1 = (hi.z - o.z) * inv.z;
+    float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(x0, x1), __builtin_fminf(y0, y1)), __builtin_fminf(z0, z1));
+    float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
+    start = __builtin_fmaxf(start, tn);
+    end = __builtin_fminf(end, tf);
+    start_out = start;
+    return !(end <= start);
+}
+
 TRT_DEV bool finite_f(float v) { return __builtin_fabsf(v) < __builtin_inff(); }
 
 // ------------------------------------------------------------------------------------------------

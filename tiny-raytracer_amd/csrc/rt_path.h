@@ -234,6 +234,25 @@ TRT_DEV void walk_fast(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Count
     }
 }
 
+// Leaf phase of the LDS-stack walks: the lane's `cnt` postponed leaves (slot k at stk[64 k] = (leaf, start)) are tested in
+// walk order, slot k in trip k, each only if its box still passes with the CURRENT t_best (t_best > start: see walk_fast).
+// Most later slots no longer pass once slot 0's hit has shrunk t_best (Cornell: 1.08 primitive tests per ray out of 3-4
+// postponed leaves, 3.4 trips at 31 % of the lanes).  Two ways of running the primitive test only as often as the busiest
+// lane needs it were measured in round 2 and rejected (same-box A/B, Cornell): a per-lane forward SCAN to the next slot that
+// still passes (fewer vector instructions, 9 % slower: ~20 scalar instructions of EXEC bookkeeping and an exposed LDS round
+// trip per slot of the divergent loop), and a survivor bit mask built by all lanes at once after slot 0 (3.7 % slower: the
+// primitive test exists twice in the kernel, and the trips it saves held two or three lanes each).
+template <int MODE, bool STATS, typename LeafTest>
+TRT_DEV void leaf_phase(const float2* stk, uint32_t cnt, Trav& tr, Counters<STATS>& ctr, LeafTest&& test) {
+    for (uint32_t k = 0; k < cnt; k++) {
+        const float2 e = stk[64u * k];
+        if (tr.t_best > e.y) {                                                             // the leaf's box test with the current t_best
+            if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
+            test(__float_as_uint(e.x));
+        }
+    }
+}
+
 // The same walk with the postponed leaves in LDS instead of registers: `stk` is this lane's slot 0, slot k lives at
 // stk[64 * k] (one 8-byte (leaf, start) pair per lane and slot, lane-contiguous: conflict-free ds_write_b64 /
 // ds_read_b64).  Putting a leaf aside costs one address, one LDS write and one add instead of the compare/select
@@ -260,13 +279,7 @@ TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
             }
         }
         if (cnt == 0u) break;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const float2 e = stk[64u * k];
-            if (tr.t_best > e.y) {                                                         // the leaf's box test with the current t_best
-                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-                trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(e.x), ctr);
-            }
-        }
+        leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
     }
 }
 
@@ -313,13 +326,7 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
             a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
             if (__builtin_amdgcn_ballot_w64(cnt + 2u > slots) != 0ull) break;    // some lane could not hold another pair: test what is pending
         }
-        for (uint32_t k = 0; k < cnt; k++) {
-            const float2 e = stk[64u * k];
-            if (tr.t_best > e.y) {                                                  // the leaf's box test with the current t_best
-                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-                trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(e.x), ctr);
-            }
-        }
+        leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
     } while (i < n);
 }
 
@@ -345,26 +352,26 @@ TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
             const uint4 q = nodes16[tr.i];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
             const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
-            const bool pass = slab_fast6(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), ray.o, tr.inv,
-                                         kTMin, tr.t_best);
+            float start;
+            const bool pass = slab_fast6_entry(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), ray.o, tr.inv,
+                                               kTMin, tr.t_best, start);
             const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
             const uint32_t next = tr.i + 1u;                                         // first child, or a leaf's successor
             if (pass && is_leaf) {
-                stk[64u * cnt] = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), 0.0f);
+                stk[64u * cnt] = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), start);
                 cnt++;
             }
             tr.i = (pass || is_leaf) ? next : q.w;
         }
         if (cnt == 0u) break;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t leaf = __float_as_uint(stk[64u * k].x);
+        // The coarse box contains the exact one, so its interval starts no later: a leaf whose COARSE start is not below the
+        // current t_best fails the exact test too and is dropped by the scan without touching memory; the others take the
+        // reference's leaf-box test on the exact f32 box, at the leaf's turn.
+        leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) {
             const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
             if constexpr (STATS) ctr.node++;
-            if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) {                  // the reference's leaf-box test, at the leaf's turn
-                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-                trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
-            }
-        }
+            if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
+        });
     }
 }
 
@@ -561,10 +568,13 @@ struct Path {
     Rng rng;
 };
 
-template <int MODE, bool STATS>
+// LAZY (SceneLayout::lazy_color): the colour is known to be +0 until the path ends - `color += attenuation * emission`
+// (cpu.rs:49-50) adds +-0 at every hit that is not a light, and the attenuation cannot overflow - so it is written once,
+// as 0 + attenuation * (light colour | background), and need not be carried from bounce to bounce.
+template <int MODE, bool STATS, bool LAZY = false>
 TRT_DEV bool shade_hit(const SceneAcc<MODE>& sc, Path& p, uint32_t prim, float t, V3 background, Counters<STATS>& ctr) {
     if (prim == PRIM_NONE) {                                           // cpu.rs:58-61
-        p.color = p.color + p.atten * background;
+        p.color = (LAZY ? v3(0.0f, 0.0f, 0.0f) : p.color) + p.atten * background;
         return true;
     }
     if constexpr (STATS) ctr.shade++;
@@ -592,8 +602,13 @@ TRT_DEV bool shade_hit(const SceneAcc<MODE>& sc, Path& p, uint32_t prim, float t
     const uint32_t kind = sc.material_kind(mat);
     const V3 albedo = v3(m.x, m.y, m.z);
     // cpu.rs:49-50: emitted() is the light's colour, None -> 0 for everything else (material/mod.rs:8-10)
-    V3 emission = (kind == TRT_LIGHT) ? albedo : v3(0.0f, 0.0f, 0.0f);
-    p.color = p.color + p.atten * emission;
+    if constexpr (LAZY) {
+        p.color = v3(0.0f, 0.0f, 0.0f);                                // what the sum is after any hit that is not a light
+        if (kind == TRT_LIGHT) p.color = v3(0.0f, 0.0f, 0.0f) + p.atten * albedo;
+    } else {
+        V3 emission = (kind == TRT_LIGHT) ? albedo : v3(0.0f, 0.0f, 0.0f);
+        p.color = p.color + p.atten * emission;
+    }
     V3 dir;
     if (kind == TRT_LAMBERTIAN) {                                      // lambertian.rs:16-22
         dir = normal + random_unit_vector(p.rng);

@@ -86,6 +86,8 @@ struct SceneLayout {
     uint32_t off_compact;       // in 16-byte elements: the culling tree as 16-byte nodes (f16 boxes rounded outward), pre-order; 0 = absent
     uint32_t off_ordered;       // in 16-byte elements: 8 pre-order arrays (one per ray-direction octant) of a free-order SAH tree, 16-byte nodes; 0 = absent
     uint32_t n_ordered_nodes;   // nodes per octant array (2 * n_leaves - 1)
+    uint32_t lazy_color;        // 1: every scattering material's albedo has |component| <= 1 (so a path's attenuation stays finite and
+                                //    `color += attenuation * 0` leaves colour at +0 until the path ends): kernels need not carry the colour
     float inv_r_min;            // 1 / smallest sphere radius (0 if that radius is not positive): tightens walk_ordered's culling band
 };
 // Largest hot blob (SceneLayout::hot_bytes) copied whole into LDS, once per workgroup; larger scenes are read from global memory.

@@ -443,6 +443,14 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
         L.blob_bytes += 8u * 16u * L.n_ordered_nodes;
     }
     L.all_finite = all_finite ? 1u : 0u;
+    // cpu.rs:49-50 adds `attenuation * emission` at EVERY hit, emission = 0 for everything but lights: the sum stays +0 as long as
+    // the attenuation is finite (x * 0 = +-0, 0 + +-0 = +0), which |albedo| <= 1 guarantees (NaN fails the comparison)
+    bool lazy = true;
+    for (const trt_material& m : w.materials) {
+        if (m.kind == TRT_LIGHT) continue;
+        lazy = lazy && fabsf(m.albedo.x) <= 1.0f && fabsf(m.albedo.y) <= 1.0f && fabsf(m.albedo.z) <= 1.0f;
+    }
+    L.lazy_color = lazy ? 1u : 0u;
     L.flat_walk = L.n_leaves <= kFlatWalkMaxLeaves ? 1u : 0u;
     if (const char* e = getenv("TRT_FLAT_WALK")) L.flat_walk = atoi(e) ? 1u : 0u;            // tuning / tests; same frames either way
 

@@ -33,7 +33,7 @@ TRT_DEV uint32_t st_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
-template <int MODE, bool STATS, int MINW = 1, int THREADS = 256, int WALK = WALK_RUNTIME>
+template <int MODE, bool STATS, int MINW = 1, int THREADS = 256, int WALK = WALK_RUNTIME, bool LAZY = false>
 __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev scd, CameraDev cam, RenderArgs ra,
                                                                              float* __restrict__ colors,
                                                                              uint32_t* __restrict__ batch_counter,
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             n_rays++;
             float t;
             const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
-            if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
+            if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
                 has_path = false;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
 // ------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t kPoolDwords = 9u;         // origin, direction, rng state, radiance slot
 
-template <int MODE, bool STATS, int MINW = 1, int THREADS = 256, int WALK = WALK_RUNTIME>
+template <int MODE, bool STATS, int MINW = 1, int THREADS = 256, int WALK = WALK_RUNTIME, bool LAZY = false>
 __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd, CameraDev cam, RenderArgs ra,
                                                                            float* __restrict__ colors,
                                                                            uint32_t* __restrict__ batch_counter,
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
             n_rays++;
             float t;
             const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
-            if (shade_hit<MODE, STATS>(sc, p, prim, t, background, ctr)) {
+            if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
                 float* c = colors + 3ull * out_idx;
                 c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
                 has_path = false;
@@ -401,13 +401,13 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         // variants run the runtime-dispatch instantiations below
         const int walk = pl.ordered ? WALK_ORDERED : pl.compact ? WALK_COMPACT : pl.flat ? WALK_FLAT : lds_stack ? WALK_LDS_STACK : WALK_REGS;
         const bool slots_ok = lds_stack || ra_all.leaf_slots == 0u || ra_all.leaf_slots >= 4u;      // WALK_REGS has 4 register slots
-        bool specialised = !stats && slots_ok && getenv("TRT_RUNTIME_WALK") == nullptr;
+        bool specialised = !stats && slots_ok && sc.L.lazy_color && getenv("TRT_RUNTIME_WALK") == nullptr;
         if (specialised) {
-            if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_FLAT>);
-            else if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_LDS_STACK) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_LDS_STACK>);
-            else if (mode == MODE_LDS && threads == 512 && w == 6 && walk == WALK_REGS) e = go(stream_sample_kernel<MODE_LDS, false, 6, 512, WALK_REGS>);
-            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_COMPACT) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_COMPACT>);
-            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_ORDERED) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_ORDERED>);
+            if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_FLAT, true>);
+            else if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_LDS_STACK) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_LDS_STACK, true>);
+            else if (mode == MODE_LDS && threads == 512 && w == 6 && walk == WALK_REGS) e = go(stream_sample_kernel<MODE_LDS, false, 6, 512, WALK_REGS, true>);
+            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_COMPACT) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true>);
+            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_ORDERED) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_ORDERED, true>);
             else specialised = false;
         }
         if (!specialised) switch (mode) {

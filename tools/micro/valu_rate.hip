@@ -23,6 +23,16 @@ __global__ __launch_bounds__(256) void spin(float* out, int iters, unsigned long
                 } else if (KIND == 1) {     // min/max/mul/add mix, like the slab test
                     a0 = fminf(a0 * m, a1); a1 = fmaxf(a1 + c, a2); a2 = fminf(a2 * m, a3); a3 = fmaxf(a3 + c, a4);
                     a4 = fminf(a4 * m, a5); a5 = fmaxf(a5 + c, a6); a6 = fminf(a6 * m, a7); a7 = fmaxf(a7 + c, a0);
+                } else if (KIND == 3) {     // packed f32: 8 v_pk_mul_f32 + 8 v_pk_add_f32 worth of work counted as 8 instructions of 2 results
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7};
+                    const f2 mm = {m, m}, cc = {c, c};
+                    p0 = p0 * mm; p1 = p1 + cc; p2 = p2 * mm; p3 = p3 + cc;
+                    p0 = p0 + cc; p1 = p1 * mm; p2 = p2 + cc; p3 = p3 * mm;
+                    a0 = p0.x; a1 = p0.y; a2 = p1.x; a3 = p1.y; a4 = p2.x; a5 = p2.y; a6 = p3.x; a7 = p3.y;
+                } else if (KIND == 4) {     // the same arithmetic unpacked: 16 instructions
+                    a0 = a0 * m; a1 = a1 * m; a2 = a2 + c; a3 = a3 + c; a4 = a4 * m; a5 = a5 * m; a6 = a6 + c; a7 = a7 + c;
+                    a0 = a0 + c; a1 = a1 + c; a2 = a2 * m; a3 = a3 * m; a4 = a4 + c; a5 = a5 + c; a6 = a6 * m; a7 = a7 * m;
                 } else {                    // dependent chain (latency)
                     a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c);
                     a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c); a0 = __builtin_fmaf(a0, m, c);
@@ -68,6 +78,8 @@ int main() {
     run<0>("fma", 4, one, d_out, ghz);
     run<1>("minmax", 4, full, d_out, ghz);
     run<1>("minmax", 4, quarter, d_out, ghz);
+    run<3>("pk 8/trip", 4, full, d_out, ghz);           // printed per 8 instructions: x1 if a pk op costs one slot
+    run<4>("unpk16/trip", 4, full, d_out, ghz);          // printed per 8: expect 2x the single-op figure
     run<2>("chain", 1, full, d_out, ghz);
     run<2>("chain", 4, full, d_out, ghz);
     return 0;
