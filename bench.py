@@ -154,11 +154,20 @@ def main():
         args.gpus = world_size
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
+    # Rehearsal of the N > 1 code path on a box with ONE GPU (TRT_BENCH_REHEARSAL=1): every rank renders its bands on
+    # cuda:0 and the collectives run on gloo through host copies.  Not a measurement - it only proves the band layout,
+    # the counters' all-reduce and the gather before the driver runs the real thing on RCCL.
+    rehearsal = world_size > 1 and os.environ.get("TRT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     trt = importlib.import_module("tiny-raytracer_amd")
     tiles = importlib.import_module("tiny-raytracer_amd.tiles")
@@ -200,10 +209,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def gather(local):
+        if rehearsal:
+            torch.cuda.synchronize()
+            return tiles.gather_image(local.cpu(), H, W, world_size, rank)
+        return tiles.gather_image(local, H, W, world_size, rank)
+
+    def reduce(t, op):
+        if rehearsal:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op)
+
     for i in range(args.warmup):
         step(i)
     if world_size > 1:                                  # warm the RCCL gather too
-        tiles.gather_image(acc, H, W, world_size, rank)
+        gather(acc)
     barrier()
     ctr.zero_()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -214,7 +237,7 @@ def main():
         ev[k][0].record(stream)
         step(args.warmup + k)
         ev[k][1].record(stream)
-    frame = tiles.gather_image(acc, H, W, world_size, rank)
+    frame = gather(acc)
     barrier()
     elapsed = time.perf_counter() - t0
     k_ms, k_n = C.c_double(0.0), C.c_uint32(0)
@@ -222,8 +245,8 @@ def main():
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     counts = ctr.clone()
     if world_size > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        reduce(t, dist.ReduceOp.MAX)
+        reduce(counts, dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total_rays = int(counts[1].item())
     total_samples = int(counts[0].item())
@@ -301,7 +324,8 @@ def main():
             "config": {"workload": f"{args.scene} {W}x{H}, depth {args.depth}, {S} spp per step (of 4096), "
                                    f"{args.backend}, reference-order BVH, seed 1",
                        "rays": total_rays, "samples": total_samples, "image_rows_per_gpu": rows_local,
-                       "parallelism": f"image bands x{world_size}" if world_size > 1 else "single GPU"},
+                       "parallelism": (f"image bands x{world_size}" + (" (REHEARSAL: all ranks on cuda:0, gloo)" if rehearsal else ""))
+                                      if world_size > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -442,6 +442,13 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
         L.off_ordered = L.blob_bytes / 16u;
         L.blob_bytes += 8u * 16u * L.n_ordered_nodes;
     }
+    {   // every offset and size of the layout is 32 bits wide: refuse scenes that do not fit instead of wrapping around
+        const uint64_t prims = (uint64_t)ns + 5ull * nq + nm;
+        const uint64_t total = 16ull * (2ull * nc + prims) + 4ull * ((uint64_t)ns + nm) + 16ull                 // hot part
+                               + 32ull * nn + 32ull * L.n_leaves                                                  // reference tree, leaf list
+                               + (want_compact ? 16ull * nc : 0ull) + (want_ordered ? 8ull * 16ull * (2ull * L.n_leaves - 1ull) : 0ull);
+        if (total > 0xFFFFFFFFull) { msg = "scene too large: the packed scene would exceed 4 GiB"; return false; }
+    }
     L.all_finite = all_finite ? 1u : 0u;
     // cpu.rs:49-50 adds `attenuation * emission` at EVERY hit, emission = 0 for everything but lights: the sum stays +0 as long as
     // the attenuation is finite (x * 0 = +-0, 0 + +-0 = +0), which |albedo| <= 1 guarantees (NaN fails the comparison)

@@ -28,10 +28,27 @@ def max_rows_local(height, world_size, band_rows=DEFAULT_BAND_ROWS):
     return max(band_layout(height, world_size, r, band_rows)["rows_local"] for r in range(world_size))
 
 
+_PLACE_CACHE = {}
+
+
+def row_placement(height, world_size, band_rows=DEFAULT_BAND_ROWS, pad_rows=None, device="cpu"):
+    """Index tensor `src` with full[y] = stacked[src[y]], where `stacked` is the [world_size * pad_rows, W, 3] concatenation
+    of the ranks' padded buffers in rank order: the whole un-interleave is ONE index_select."""
+    pad_rows = pad_rows or max_rows_local(height, world_size, band_rows)
+    key = (height, world_size, band_rows, pad_rows, str(device))
+    if key not in _PLACE_CACHE:
+        src = torch.empty(height, dtype=torch.long)
+        for r in range(world_size):
+            rows = band_layout(height, world_size, r, band_rows)["rows"]
+            src[torch.tensor(rows, dtype=torch.long)] = r * pad_rows + torch.arange(len(rows), dtype=torch.long)
+        _PLACE_CACHE[key] = src.to(device)
+    return _PLACE_CACHE[key]
+
+
 def gather_image(local, height, width, world_size, rank, band_rows=DEFAULT_BAND_ROWS, group=None):
-    """One gather of the per-rank accumulators to rank 0, then un-interleave into [height, width, 3].
-    `local` is this rank's [rows_local, width, 3] f32 tensor.  Returns the full image on rank 0, None elsewhere.
-    Ranks may own different row counts (ragged last band), so buffers are padded to the common maximum."""
+    """One gather of the per-rank accumulators to rank 0, then one index_select that puts every row in its place.
+    `local` is this rank's [rows_local, width, 3] f32 tensor.  Returns the full [height, width, 3] image on rank 0, None
+    elsewhere.  Ranks may own different row counts (ragged last band), so buffers are padded to the common maximum."""
     if world_size == 1:
         return local
     pad_rows = max_rows_local(height, world_size, band_rows)
@@ -41,13 +58,9 @@ def gather_image(local, height, width, world_size, rank, band_rows=DEFAULT_BAND_
         send[: local.shape[0]] = local
     send = send.contiguous()
     if rank == 0:
-        recv = [torch.empty_like(send) for _ in range(world_size)]
+        stacked = torch.empty((world_size * pad_rows, width, 3), dtype=local.dtype, device=local.device)
+        recv = list(stacked.view(world_size, pad_rows, width, 3).unbind(0))          # views: the gather fills `stacked` in place
         dist.gather(send, gather_list=recv, dst=0, group=group)
-        full = torch.empty((height, width, 3), dtype=local.dtype, device=local.device)
-        for r in range(world_size):
-            lay = band_layout(height, world_size, r, band_rows)
-            idx = torch.tensor(lay["rows"], dtype=torch.long, device=local.device)
-            full[idx] = recv[r][: lay["rows_local"]]
-        return full
+        return stacked.index_select(0, row_placement(height, world_size, band_rows, pad_rows, local.device))
     dist.gather(send, gather_list=None, dst=0, group=group)
     return None
