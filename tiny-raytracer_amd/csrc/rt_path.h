@@ -57,13 +57,37 @@ TRT_DEV void stage_scene_to_lds(const SceneDev& sc) {
     }
 }
 
+// Diagnostic build only (-DTRT_PHASE_CLOCK, tools/phase_clock.sh): shader-clock time per phase of the streamed kernels, per wave
+// (s_memtime at the phase boundaries, summed into counters[12..15]: 0 = fetch / generate, 1 = box steps, 2 = leaf phase,
+// 3 = shade).  The instrumentation itself costs ~10 % (guides/MI355X_MICROARCH.md); the split is what is read off it.
+#ifdef TRT_PHASE_CLOCK
+struct PhaseClock {
+    uint32_t t[4] = {0u, 0u, 0u, 0u};
+    uint64_t last = 0;
+    TRT_DEV void start() { last = __builtin_amdgcn_s_memtime(); }
+    TRT_DEV void mark(int phase) { const uint64_t now = __builtin_amdgcn_s_memtime(); t[phase] += (uint32_t)(now - last); last = now; }
+};
+#define TRT_CLK_START(c) (c).clk.start()
+#define TRT_CLK(c, phase) (c).clk.mark(phase)
+#else
+#define TRT_CLK_START(c) ((void)0)
+#define TRT_CLK(c, phase) ((void)0)
+#endif
+
 template <bool STATS>
 struct Counters {
     uint32_t node = 0, sphere = 0, quad_plane = 0, quad_inside = 0, shade = 0;
     uint32_t w_rounds = 0, w_steps = 0, w_leaf = 0, w_gen = 0;     // wave-level trips, counted by the first active lane
+#ifdef TRT_PHASE_CLOCK
+    PhaseClock clk;
+#endif
 };
 template <>
-struct Counters<false> {};
+struct Counters<false> {
+#ifdef TRT_PHASE_CLOCK
+    PhaseClock clk;
+#endif
+};
 
 TRT_DEV bool first_active_lane() {
     return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true));
@@ -135,21 +159,24 @@ TRT_DEV void trav_leaf(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, uint3
     const uint32_t idx = leaf & PRIM_INDEX_MASK;
     if (leaf & PRIM_QUAD_BIT) {                                        // Quad::hit, quad.rs:33-54
         if constexpr (STATS) ctr.quad_plane++;
-        float4 q0 = sc.quad(0, idx);
-        V3 nrm = v3(q0.x, q0.y, q0.z);
-        float dir_norm = dot(ray.d, nrm);
-        float t = (q0.w - dot(ray.o, nrm)) / dir_norm;
-        if (kTMin <= t && t < tr.t_best) {
-            if constexpr (STATS) ctr.quad_inside++;
-            float4 q1 = sc.quad(1, idx), q2 = sc.quad(2, idx), q3 = sc.quad(3, idx), q4 = sc.quad(4, idx);
-            V3 p = ray_at(ray, t) - v3(q1.x, q1.y, q1.z);
-            V3 vv = v3(q2.x, q2.y, q2.z), ww = v3(q2.w, q3.x, q3.y), uu = v3(q3.z, q3.w, q4.x);
-            float planar_x = dot(cross(p, vv), ww);
-            float planar_y = dot(cross(uu, p), ww);
-            if (0.0f <= planar_x && planar_x < 1.0f && 0.0f <= planar_y && planar_y < 1.0f) {
-                tr.t_best = t;
-                tr.prim_best = leaf;
-            }
+        // Branch-free: all five planes are requested at once and the inside test is evaluated whatever the plane stage says.
+        // Nearly every quad whose box still passes also passes the plane stage (Cornell: 1.08 plane tests and 0.97 inside
+        // tests per ray), so the branch saved next to nothing and cost a second LDS round trip in a phase that is
+        // latency-bound.  A t outside the range (or inf / NaN from a ray parallel to the plane) only feeds values that the
+        // final conjunction discards: the same quads are accepted as with quad.rs:37,41's early returns.
+        const float4 q0 = sc.quad(0, idx), q1 = sc.quad(1, idx), q2 = sc.quad(2, idx), q3 = sc.quad(3, idx), q4 = sc.quad(4, idx);
+        const V3 nrm = v3(q0.x, q0.y, q0.z);
+        const float dir_norm = dot(ray.d, nrm);
+        const float t = (q0.w - dot(ray.o, nrm)) / dir_norm;
+        const bool in_range = (kTMin <= t) & (t < tr.t_best);
+        if constexpr (STATS) { if (in_range) ctr.quad_inside++; }
+        const V3 p = ray_at(ray, t) - v3(q1.x, q1.y, q1.z);
+        const V3 vv = v3(q2.x, q2.y, q2.z), ww = v3(q2.w, q3.x, q3.y), uu = v3(q3.z, q3.w, q4.x);
+        const float planar_x = dot(cross(p, vv), ww);
+        const float planar_y = dot(cross(uu, p), ww);
+        if (in_range & (0.0f <= planar_x) & (planar_x < 1.0f) & (0.0f <= planar_y) & (planar_y < 1.0f)) {
+            tr.t_best = t;
+            tr.prim_best = leaf;
         }
     } else {                                                           // Sphere::hit, sphere.rs:29-54
         if constexpr (STATS) ctr.sphere++;
@@ -245,10 +272,14 @@ TRT_DEV void walk_fast(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Count
 template <int MODE, bool STATS, typename LeafTest>
 TRT_DEV void leaf_phase(const float2* stk, uint32_t cnt, Trav& tr, Counters<STATS>& ctr, LeafTest&& test) {
     for (uint32_t k = 0; k < cnt; k++) {
-        const float2 e = stk[64u * k];
-        if (tr.t_best > e.y) {                                                             // the leaf's box test with the current t_best
+        // one 8-byte LDS read for (leaf, start): read as two words the compiler fetches `start`, waits, branches, fetches `leaf`
+        // and waits again - two LDS round trips in a phase that is latency-bound (30 % of Cornell's wave time at 15 % of its
+        // vector instructions)
+        const unsigned long long e = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(stk + 64u * k));
+        const float start = __uint_as_float((uint32_t)(e >> 32));
+        if (tr.t_best > start) {                                                           // the leaf's box test with the current t_best
             if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-            test(__float_as_uint(e.x));
+            test((uint32_t)e);
         }
     }
 }
@@ -278,8 +309,10 @@ TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
                 cnt++;
             }
         }
+        TRT_CLK(ctr, 1);
         if (cnt == 0u) break;
         leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
+        TRT_CLK(ctr, 2);
     }
 }
 
@@ -326,7 +359,9 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
             a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
             if (__builtin_amdgcn_ballot_w64(cnt + 2u > slots) != 0ull) break;    // some lane could not hold another pair: test what is pending
         }
+        TRT_CLK(ctr, 1);
         leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
+        TRT_CLK(ctr, 2);
     } while (i < n);
 }
 
@@ -363,6 +398,7 @@ TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
             }
             tr.i = (pass || is_leaf) ? next : q.w;
         }
+        TRT_CLK(ctr, 1);
         if (cnt == 0u) break;
         // The coarse box contains the exact one, so its interval starts no later: a leaf whose COARSE start is not below the
         // current t_best fails the exact test too and is dropped by the scan without touching memory; the others take the
@@ -372,6 +408,7 @@ TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
             if constexpr (STATS) ctr.node++;
             if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
         });
+        TRT_CLK(ctr, 2);
     }
 }
 
@@ -696,6 +733,9 @@ TRT_DEV void flush_counters(unsigned long long* counters, uint32_t samples, uint
         if (s) atomicAdd(&counters[CTR_SAMPLES], (unsigned long long)s);
         if (r) atomicAdd(&counters[CTR_RAYS], (unsigned long long)r);
     }
+#ifdef TRT_PHASE_CLOCK
+    if (lane0) { for (int k = 0; k < 4; k++) atomicAdd(&counters[12 + k], (unsigned long long)ctr.clk.t[k]); }
+#endif
     if constexpr (STATS) {
         uint32_t v[9] = {ctr.node, ctr.sphere, ctr.quad_plane, ctr.quad_inside, ctr.shade, ctr.w_rounds, ctr.w_steps, ctr.w_leaf, ctr.w_gen};
         const int slot[9] = {CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_W_ROUNDS, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN};

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
 
+    TRT_CLK_START(ctr);
     for (;;) {
         // ---- lanes without a path take pool entries; an empty pool is refilled by the whole wave ----
         for (;;) {
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
             pool_count -= taken;
         }
         if (__builtin_amdgcn_ballot_w64(has_path) == 0ull) break;                         // nothing left to trace: the batches are used up
+        TRT_CLK(ctr, 0);
         if (has_path) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             n_rays++;
@@ -247,6 +249,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                 has_path = false;
             }
         }
+        TRT_CLK(ctr, 3);
     }
     flush_counters<STATS>(counters, n_samples, n_rays, ctr);
 }
