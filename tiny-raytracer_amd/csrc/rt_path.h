@@ -39,7 +39,8 @@ struct SceneAcc {
     // reference tree: always read from HBM/L2 (counting kernels and NaN-prone rays only)
     TRT_DEV void ref_node(uint32_t i, float4& a, float4& b) const { a = blob[L.off_ref_nodes + 2u * i]; b = blob[L.off_ref_nodes + 2u * i + 1u]; }
     TRT_DEV float4 sphere(uint32_t i) const { return f4(L.off_sphere + i); }
-    TRT_DEV float4 quad(uint32_t plane, uint32_t i) const { return f4(L.off_quad + plane * L.n_quads + i); }
+    // a quad is five consecutive elements (scene.h): one address per quad, the planes at immediate offsets
+    TRT_DEV float4 quad(uint32_t plane, uint32_t i) const { return f4(L.off_quad + 5u * i + plane); }
     TRT_DEV float4 material(uint32_t i) const { return f4(L.off_material + i); }
     TRT_DEV uint32_t sphere_material(uint32_t i) const { return u32(L.off_sphere_mat + i); }
     TRT_DEV uint32_t material_kind(uint32_t i) const { return u32(L.off_material_kind + i); }
@@ -271,10 +272,10 @@ TRT_DEV void walk_fast(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Count
 // primitive test exists twice in the kernel, and the trips it saves held two or three lanes each).
 template <int MODE, bool STATS, typename LeafTest>
 TRT_DEV void leaf_phase(const float2* stk, uint32_t cnt, Trav& tr, Counters<STATS>& ctr, LeafTest&& test) {
+    // One 8-byte LDS read for (leaf, start): read as two words the compiler fetches `start`, waits, branches, fetches `leaf` and
+    // waits again - two LDS round trips in a phase that is latency-bound (30 % of Cornell's wave time at 15 % of its vector
+    // instructions).  (Requesting slot k+1 before slot k's primitive is tested was measured too: no gain.)
     for (uint32_t k = 0; k < cnt; k++) {
-        // one 8-byte LDS read for (leaf, start): read as two words the compiler fetches `start`, waits, branches, fetches `leaf`
-        // and waits again - two LDS round trips in a phase that is latency-bound (30 % of Cornell's wave time at 15 % of its
-        // vector instructions)
         const unsigned long long e = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(stk + 64u * k));
         const float start = __uint_as_float((uint32_t)(e >> 32));
         if (tr.t_best > start) {                                                           // the leaf's box test with the current t_best
@@ -383,6 +384,10 @@ TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
     const uint32_t n = sc.L.n_cull_nodes;
     for (;;) {
         uint32_t cnt = 0;
+        // (Measured and rejected in round 2: requesting nodes i and i + 1 together and stepping i + 1 from the data already
+        // there when the walk goes on to it - the successor IS the next node whenever the box passes or the node is a leaf.  It
+        // shortens the chain of dependent loads by a third, and is 15 % slower on the 100 k-sphere scene: twice the vector-memory
+        // instructions, and the second step runs with about half of the lanes.)
         while (tr.i < n && cnt < slots) {
             const uint4 q = nodes16[tr.i];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }

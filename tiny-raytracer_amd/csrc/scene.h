@@ -57,11 +57,13 @@ struct World {
 //               2i+1: (max.y, max.z, bits(skip), bits(link))    link: NODE_INNER_BIT | first child, or kind bit | primitive index
 //               the first n_top_nodes are the tree's top levels, level by level; the rest follow in pre-order
 //   [sphere: ns] (center.xyz, radius)
-//   [quad plane 0: nq] (n.xyz, d)            Quad::hit stage 1   (quad.rs:34-37)
-//   [quad plane 1: nq] (corner.xyz, bits(material))
-//   [quad plane 2: nq] (v.xyz, w.x)          stage 2             (quad.rs:38-41)
-//   [quad plane 3: nq] (w.y, w.z, u.x, u.y)
-//   [quad plane 4: nq] (u.z, n_unit.xyz)     HitRecord normal    (hittable/mod.rs:35-40)
+//   [quad: 5 nq] one record of five consecutive elements per quad (every test and every shade reads all of them: one address,
+//               the elements at immediate offsets, 80 contiguous bytes when the scene is read from global memory)
+//               +0 (n.xyz, d)                 Quad::hit stage 1   (quad.rs:34-37)
+//               +1 (corner.xyz, bits(material))
+//               +2 (v.xyz, w.x)               stage 2             (quad.rs:38-41)
+//               +3 (w.y, w.z, u.x, u.y)
+//               +4 (u.z, n_unit.xyz)          HitRecord normal    (hittable/mod.rs:35-40)
 //   [material: nm] (albedo.rgb, param)
 //   [sphere_material: ns] u32   [material_kind: nm] u32          (padded to 16 bytes)   <- hot_bytes end here
 //   [reference nodes: 2n] same node format

@@ -547,11 +547,8 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     dump_tree(out.culling, cb.node_box, cull_prim_geo, cb.node_skip);
     for (uint32_t i = 0; i < ns; i++) { f4[L.off_sphere + i] = spheres[i]; u32[L.off_sphere_mat + i] = sphere_mat[i]; }
     for (uint32_t i = 0; i < nq; i++) {
-        f4[L.off_quad + 0 * nq + i] = q0[i];
-        f4[L.off_quad + 1 * nq + i] = q1[i];
-        f4[L.off_quad + 2 * nq + i] = q2[i];
-        f4[L.off_quad + 3 * nq + i] = q3[i];
-        f4[L.off_quad + 4 * nq + i] = q4[i];
+        F4* q = f4 + L.off_quad + 5u * (size_t)i;                 // one record of five elements per quad
+        q[0] = q0[i]; q[1] = q1[i]; q[2] = q2[i]; q[3] = q3[i]; q[4] = q4[i];
     }
     for (uint32_t i = 0; i < nm; i++) {
         const trt_material& m = w.materials[i];
