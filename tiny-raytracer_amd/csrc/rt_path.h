@@ -268,8 +268,9 @@ TRT_DEV void walk_fast(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Count
 // postponed leaves, 3.4 trips at 31 % of the lanes).  Two ways of running the primitive test only as often as the busiest
 // lane needs it were measured in round 2 and rejected (same-box A/B, Cornell): a per-lane forward SCAN to the next slot that
 // still passes (fewer vector instructions, 9 % slower: ~20 scalar instructions of EXEC bookkeeping and an exposed LDS round
-// trip per slot of the divergent loop), and a survivor bit mask built by all lanes at once after slot 0 (3.7 % slower: the
-// primitive test exists twice in the kernel, and the trips it saves held two or three lanes each).
+// trip per slot of the divergent loop), and a survivor bit mask built by all lanes at once after slot 0 (3.7 % slower with
+// a second copy of the primitive test for slot 0, 6 % slower with a single test site: the ballot-driven loop and the
+// mask bookkeeping cost more than the trips they save, which held two or three lanes each).
 template <int MODE, bool STATS, typename LeafTest>
 TRT_DEV void leaf_phase(const float2* stk, uint32_t cnt, Trav& tr, Counters<STATS>& ctr, LeafTest&& test) {
     // One 8-byte LDS read for (leaf, start): read as two words the compiler fetches `start`, waits, branches, fetches `leaf` and
