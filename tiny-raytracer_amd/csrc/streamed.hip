@@ -317,6 +317,12 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
     const bool flat = L.flat_walk && !ra_all.ref_tree;
     uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 7u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
     if (flat && slots < 2u) slots = 2u;                                         // walk_flat pushes up to two leaves per trip
+    if (flat && ra_all.leaf_slots == 0u && mode == MODE_LDS && threads == 256) {
+        // the default depth gives way to occupancy: the deepest stack (<= 7, >= 4) with which stack + ray pool + scene copy of
+        // all the CU's workgroups fit its 160 KB of LDS (Cornell: 7 slots at 6 waves per SIMD, 5 at 7, 4 at 8)
+        const size_t pool_b = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
+        while (slots > 4u && (((scene_bytes + 15u) & ~(size_t)15u) + (size_t)threads * slots * sizeof(float2) + pool_b) * wg_per_cu > 160u * 1024u) slots--;
+    }
     const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
     const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
     // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
@@ -334,7 +340,7 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
     // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack and 256-lane workgroups (LDS scenes at 6
     // waves per SIMD, global-memory scenes at 8), and must not cost a resident workgroup either
     const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w == 6) || (mode == MODE_GLOBAL && w == 8));
+    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && w == 8));
     if (const char* env = getenv("TRT_RAY_POOL")) pool = pool && atoi(env) != 0;
     if (pool) pool = (uint32_t)(160u * 1024u / (with_stack + pool_bytes)) >= wg_per_cu;
     const size_t lds_bytes = lds_stack ? with_stack + (pool ? pool_bytes : 0u) : scene_bytes;
@@ -407,6 +413,8 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         bool specialised = !stats && slots_ok && sc.L.lazy_color && getenv("TRT_RUNTIME_WALK") == nullptr;
         if (specialised) {
             if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_FLAT, true>);
+            else if (mode == MODE_LDS && threads == 256 && w == 7 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 7, 256, WALK_FLAT, true>);
+            else if (mode == MODE_LDS && threads == 256 && w >= 8 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 8, 256, WALK_FLAT, true>);
             else if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_LDS_STACK) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_LDS_STACK, true>);
             else if (mode == MODE_LDS && threads == 512 && w == 6 && walk == WALK_REGS) e = go(stream_sample_kernel<MODE_LDS, false, 6, 512, WALK_REGS, true>);
             else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_COMPACT) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true>);
