@@ -271,13 +271,16 @@ TRT_DEV void walk_fast(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Count
 // trip per slot of the divergent loop), and a survivor bit mask built by all lanes at once after slot 0 (3.7 % slower with
 // a second copy of the primitive test for slot 0, 6 % slower with a single test site: the ballot-driven loop and the
 // mask bookkeeping cost more than the trips they save, which held two or three lanes each).
+// The stack is a bump pointer: `top` is the lane's first free slot (slots are 64 float2 apart), so a push is one LDS write
+// and one add, and nothing but the pointer is carried (a slot COUNT cost a second add and a shift-add per push: 18 pushes
+// per Cornell walk).
 template <int MODE, bool STATS, typename LeafTest>
-TRT_DEV void leaf_phase(const float2* stk, uint32_t cnt, Trav& tr, Counters<STATS>& ctr, LeafTest&& test) {
+TRT_DEV void leaf_phase(const float2* stk, const float2* top, Trav& tr, Counters<STATS>& ctr, LeafTest&& test) {
     // One 8-byte LDS read for (leaf, start): read as two words the compiler fetches `start`, waits, branches, fetches `leaf` and
     // waits again - two LDS round trips in a phase that is latency-bound (30 % of Cornell's wave time at 15 % of its vector
     // instructions).  (Requesting slot k+1 before slot k's primitive is tested was measured too: no gain.)
-    for (uint32_t k = 0; k < cnt; k++) {
-        const unsigned long long e = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(stk + 64u * k));
+    for (const float2* slot = stk; slot != top; slot += 64) {
+        const unsigned long long e = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(slot));
         const float start = __uint_as_float((uint32_t)(e >> 32));
         if (tr.t_best > start) {                                                           // the leaf's box test with the current t_best
             if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
@@ -295,9 +298,10 @@ TRT_DEV void leaf_phase(const float2* stk, uint32_t cnt, Trav& tr, Counters<STAT
 template <int MODE, bool STATS>
 TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
     const uint32_t n = sc.L.n_cull_nodes;
+    float2* const limit = stk + 64u * slots;
     for (;;) {
-        uint32_t cnt = 0;
-        while (tr.i < n && cnt < slots) {
+        float2* top = stk;
+        while (tr.i < n && top != limit) {
             float4 na, nb;
             sc.node(tr.i, na, nb);
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
@@ -307,13 +311,13 @@ TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
             const bool inner = (link & NODE_INNER_BIT) != 0u;
             tr.i = (pass && inner) ? (link & ~NODE_INNER_BIT) : __float_as_uint(nb.z);     // descend, or skip (a leaf's skip is its successor)
             if (pass && !inner) {
-                stk[64u * cnt] = make_float2(nb.w, start);
-                cnt++;
+                *top = make_float2(nb.w, start);
+                top += 64;
             }
         }
         TRT_CLK(ctr, 1);
-        if (cnt == 0u) break;
-        leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
+        if (top == stk) break;
+        leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
         TRT_CLK(ctr, 2);
     }
 }
@@ -338,8 +342,9 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
     float4 a0 = leaf_list[0], b0 = leaf_list[1];
     const uint32_t i1 = last < 1u ? last : 1u;
     float4 a1 = leaf_list[2u * i1], b1 = leaf_list[2u * i1 + 1u];
+    float2* const limit = stk + 64u * (slots - 2u);      // a lane whose top is beyond it cannot hold another pair (slots >= 2)
     do {
-        uint32_t cnt = 0;
+        float2* top = stk;
         for (; i < n;) {
             // request the next pair (indices clamped to the list: a harmless re-read at the end)
             const uint32_t j0 = i + 2u < last ? i + 2u : last, j1 = i + 3u < last ? i + 3u : last;
@@ -347,22 +352,22 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
             float start;
             if (slab_fast_entry(a0, b0, ray.o, tr.inv, kTMin, tr.t_best, start)) {
-                stk[64u * cnt] = make_float2(b0.w, start);
-                cnt++;
+                *top = make_float2(b0.w, start);
+                top += 64;
             }
             if (i + 1u < n) {
                 if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
                 if (slab_fast_entry(a1, b1, ray.o, tr.inv, kTMin, tr.t_best, start)) {
-                    stk[64u * cnt] = make_float2(b1.w, start);
-                    cnt++;
+                    *top = make_float2(b1.w, start);
+                    top += 64;
                 }
             }
             i += 2u;
             a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
-            if (__builtin_amdgcn_ballot_w64(cnt + 2u > slots) != 0ull) break;    // some lane could not hold another pair: test what is pending
+            if (__builtin_amdgcn_ballot_w64(top > limit) != 0ull) break;         // some lane could not hold another pair: test what is pending
         }
         TRT_CLK(ctr, 1);
-        leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
+        leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
         TRT_CLK(ctr, 2);
     } while (i < n);
 }
@@ -383,13 +388,14 @@ template <int MODE, bool STATS>
 TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
                           const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
     const uint32_t n = sc.L.n_cull_nodes;
+    float2* const limit = stk + 64u * slots;
     for (;;) {
-        uint32_t cnt = 0;
+        float2* top = stk;
         // (Measured and rejected in round 2: requesting nodes i and i + 1 together and stepping i + 1 from the data already
         // there when the walk goes on to it - the successor IS the next node whenever the box passes or the node is a leaf.  It
         // shortens the chain of dependent loads by a third, and is 15 % slower on the 100 k-sphere scene: twice the vector-memory
         // instructions, and the second step runs with about half of the lanes.)
-        while (tr.i < n && cnt < slots) {
+        while (tr.i < n && top != limit) {
             const uint4 q = nodes16[tr.i];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
             const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
@@ -399,17 +405,17 @@ TRT_DEV void walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
             const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
             const uint32_t next = tr.i + 1u;                                         // first child, or a leaf's successor
             if (pass && is_leaf) {
-                stk[64u * cnt] = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), start);
-                cnt++;
+                *top = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), start);
+                top += 64;
             }
             tr.i = (pass || is_leaf) ? next : q.w;
         }
         TRT_CLK(ctr, 1);
-        if (cnt == 0u) break;
+        if (top == stk) break;
         // The coarse box contains the exact one, so its interval starts no later: a leaf whose COARSE start is not below the
         // current t_best fails the exact test too and is dropped by the scan without touching memory; the others take the
         // reference's leaf-box test on the exact f32 box, at the leaf's turn.
-        leaf_phase<MODE, STATS>(stk, cnt, tr, ctr, [&](uint32_t leaf) {
+        leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) {
             const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
             if constexpr (STATS) ctr.node++;
             if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
