@@ -301,9 +301,16 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
     StreamPlan pl{};
     const size_t scene_bytes = scene_lds_bytes(L);
     const int mode = scene_mode(L);
-    // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies, 512-lane workgroups sharing a big
-    // LDS copy between 8 waves, 8 waves per SIMD for scenes read from global memory
-    const int threads = (mode == MODE_LDS && L.hot_bytes > 20u * 1024u) ? 512 : 256;
+    // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies; a big LDS copy (> 20 KB) is shared by
+    // more waves: 768 lanes (12 waves, two workgroups per CU = 6 waves per SIMD) if the copy and a 4-slot LDS leaf stack
+    // fit twice into the CU's 160 KB (random-spheres: 49.6 + 24 KB; 19.0 Gray/s against 18.0 for 512 lanes with register
+    // slots and 18.7 for 1024 lanes at 8 waves per SIMD, one box: tools/sweep_rs.sh), else 512 lanes with the slots in registers;
+    // 8 waves per SIMD for scenes read from global memory
+    int threads = 256;
+    if (mode == MODE_LDS && L.hot_bytes > 20u * 1024u) {
+        threads = (((scene_bytes + 15u) & ~(size_t)15u) + 768u * 4u * sizeof(float2)) * 2u <= 160u * 1024u && ra_all.lds_leaf_stack != 0u ? 768 : 512;
+        if (const char* env = getenv("TRT_BIG_THREADS")) { const int t = atoi(env); if (t == 512 || t == 768) threads = t; }
+    }
     // LDS scenes: 6 waves per SIMD (80 VGPRs, 21 spilled) beat 7 (72 VGPRs, 38 spilled) by 3 % and 5 (no spills) by 2 % on
     // Cornell.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box step once the
     // compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6, 2.29 at 8)
@@ -311,6 +318,7 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
     if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
     if (w < 5) w = 5;
     if (threads == 512 && w > 6) w = 6;
+    if (threads == 768) w = 6;
     uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
     // slots of the LDS stack: 4 for tree walks; 7 for the lock-step leaf list, whose t_best stays stale for a whole walk
     // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12) and which steps two leaves per trip, so a lane must have two free
@@ -322,6 +330,9 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
         // all the CU's workgroups fit its 160 KB of LDS (Cornell: 7 slots at 6 waves per SIMD, 5 at 7, 4 at 8)
         const size_t pool_b = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
         while (slots > 4u && (((scene_bytes + 15u) & ~(size_t)15u) + (size_t)threads * slots * sizeof(float2) + pool_b) * wg_per_cu > 160u * 1024u) slots--;
+    }
+    if (threads > 512 && ra_all.leaf_slots == 0u) {
+        while (slots > 3u && (((scene_bytes + 15u) & ~(size_t)15u) + (size_t)threads * slots * sizeof(float2)) * wg_per_cu > 160u * 1024u) slots--;
     }
     const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
     const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
@@ -417,13 +428,15 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
             else if (mode == MODE_LDS && threads == 256 && w >= 8 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 8, 256, WALK_FLAT, true>);
             else if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_LDS_STACK) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_LDS_STACK, true>);
             else if (mode == MODE_LDS && threads == 512 && w == 6 && walk == WALK_REGS) e = go(stream_sample_kernel<MODE_LDS, false, 6, 512, WALK_REGS, true>);
+            else if (mode == MODE_LDS && threads == 768 && walk == WALK_LDS_STACK && !pool) e = go(stream_sample_kernel<MODE_LDS, false, 6, 768, WALK_LDS_STACK, true>);
             else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_COMPACT) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true>);
             else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_ORDERED) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_ORDERED, true>);
             else specialised = false;
         }
         if (!specialised) switch (mode) {
             case MODE_LDS:
-                if (threads == 512) {
+                if (threads == 768) e = launch_pick<MODE_LDS, 6, 768>(stats, go);
+                else if (threads == 512) {
                     if (w >= 6) e = launch_pick<MODE_LDS, 6, 512>(stats, go);
                     else e = launch_pick<MODE_LDS, 5, 512>(stats, go);
                 } else if (w >= 7) e = launch_pick<MODE_LDS, 7, 256>(stats, go);
