@@ -293,7 +293,7 @@ def main():
         if prof is not None and not stale and world_size == 1:
             insts = prof["SQ_INSTS_VALU"]
             valu_rate = insts / (avg_ms * 1e-3) / 1e9
-            lanes = prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_ACTIVE_INST_VALU"] * 16.0 if prof.get("SQ_ACTIVE_INST_VALU") else None
+            lanes = prof["SQ_THREAD_CYCLES_VALU"] / insts if prof.get("SQ_THREAD_CYCLES_VALU") else None      # active lanes per VALU instruction
             hbm = prof["hbm_bytes_per_launch"]
             roofline.update({
                 "achieved": round(valu_rate, 1), "frac": round(valu_rate / VALU_PEAK_GINST, 4), "traffic": int(hbm),
