@@ -299,4 +299,22 @@ impl Renderer {
         check(unsafe { sys::trt_render(scene, &camera.pod, &params, data.as_mut_ptr(), ptr::null_mut()) })?;
         Ok(Image { width, height, gamma: 2.2, data })
     }
+
+    /// The same call over `ndev` GPUs of the node (0 = every visible device): the image's 16-row bands are dealt round-robin
+    /// over the devices and every finished band is copied to its place in the frame (trt_render_multi).
+    pub fn render_multi(&self, camera: &Camera, world: &mut World, ndev: u32) -> Result<Image, Error> {
+        let (width, height) = camera.get_image_size();
+        let scene = world.get_bvh()?;
+        let params = sys::trt_render_params {
+            samples_per_pixel: self.samples_per_pixel as u32,
+            max_bounces: self.max_bounces as u32,
+            background: self.background_color.raw(),
+            seed: self.seed,
+            backend: self.backend,
+            ..Default::default()
+        };
+        let mut data = vec![0.0 as Float; width * height * 3];
+        check(unsafe { sys::trt_render_multi(scene, &camera.pod, &params, ptr::null(), ndev, data.as_mut_ptr(), ptr::null_mut()) })?;
+        Ok(Image { width, height, gamma: 2.2, data })
+    }
 }

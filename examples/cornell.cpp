@@ -32,6 +32,7 @@ static void build_objects(World& world) {                         // src/main.rs
 int main(int argc, char** argv) {
     const uint32_t w = argc > 2 ? (uint32_t)std::atoi(argv[1]) : 300, h = argc > 2 ? (uint32_t)std::atoi(argv[2]) : 300;
     const uint32_t spp = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 300;
+    const int ngpu = argc > 4 ? std::atoi(argv[4]) : 1;                 // 0 = every GPU of the node (trt_render_multi)
     try {
         World world;
         build_materials(world);
@@ -39,7 +40,8 @@ int main(int argc, char** argv) {
         Camera camera(140.0f, 0.6f, Vec3(50, 50, -140), Vec3(50, 50, 0), Vec3(0, 1, 0), 40.0f, w, h);
         Renderer instance(spp, 8, 20, true, Vec3::new_diagonal(0.001f));
         trt_stats st{};
-        Image image = instance.render(camera, world, &st);
+        Image image = ngpu == 1 ? instance.render(camera, world, &st)
+                                : instance.render_multi(camera, world, ngpu > 0 ? std::vector<int>((size_t)ngpu, 0) : std::vector<int>{}, &st);
         image.save("output.png");                                      // src/main.rs:20
         std::printf("%ux%u, %u spp: %llu rays in %.2f ms (%.1f Mray/s) -> output.png\n", w, h, spp, (unsigned long long)st.rays,
                     st.kernel_ms, st.rays / st.kernel_ms / 1e3);

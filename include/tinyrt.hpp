@@ -216,6 +216,13 @@ public:
         check(trt_render(world.get_bvh(), &camera.pod, &params_, img.linear(), stats));
         return img;
     }
+    // The same call over several GPUs of the node (trt_render_multi): `devices` empty = every visible device.
+    Image render_multi(const Camera& camera, World& world, const std::vector<int>& devices = {}, trt_stats* stats = nullptr) const {
+        Image img(camera.pod.width, camera.pod.height);
+        check(trt_render_multi(world.get_bvh(), &camera.pod, &params_, devices.empty() ? nullptr : devices.data(),
+                               (uint32_t)devices.size(), img.linear(), stats));
+        return img;
+    }
     trt_render_params& params() { return params_; }
 
 private:

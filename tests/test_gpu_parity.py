@@ -311,6 +311,11 @@ def test_cpp_mirror_renders_the_same_frame(trt, tmp_path):
     pw, pcam = trt.world_from_description(desc)
     img = trt.Renderer(5, 8, 20, True, (0.001, 0.001, 0.001)).render(pcam, pw)
     assert got.shape == (56, 72, 3) and np.array_equal(got, img.to_u8())
+    # the same binary over three shards (tinyrt::Renderer::render_multi -> trt_render_multi): the same PNG
+    r = subprocess.run([exe, "72", "56", "5", "3"], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    again = np.asarray(PILImage.open(tmp_path / "output.png").convert("RGB"))
+    assert np.array_equal(again, got)
 
 
 def test_default_backend_is_auto_and_matches_the_oracle(trt, orc):
