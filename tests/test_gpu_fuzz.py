@@ -137,3 +137,17 @@ def test_global_memory_walks_agree_on_many_rays(trt, monkeypatch, spheres_only):
             assert st[k] == ref_stats[k], (tag, k)
         if near_first:
             assert st["node_tests"] < 0.7 * ref_stats["node_tests"], tag              # the point of it: far fewer box tests
+
+
+def test_shared_reciprocal_division_is_ieee_division(tmp_path):
+    """rt_device.h div_shared (Vec3::normalized's three divisions sharing one refined reciprocal) must give the bits of `/`:
+    tools/micro/div_exact.hip compares the sequence with IEEE division on ~1e10 random operand pairs (exponents in [-48, 48],
+    edge mantissas included) on the device and exits non-zero on any mismatch."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "div_exact")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-DRANGE=48", "-o", exe,
+                    os.path.join(root, "tools", "micro", "div_exact.hip")], check=True)
+    r = subprocess.run([exe, "512"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr

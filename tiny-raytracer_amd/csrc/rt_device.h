@@ -36,7 +36,35 @@ TRT_DEV V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
 TRT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }          // vec3.rs:49-51
 TRT_DEV float sqlen(V3 a) { return dot(a, a); }                                      // vec3.rs:41-43
 TRT_DEV float length(V3 a) { return __builtin_sqrtf(sqlen(a)); }                     // vec3.rs:37-39
-TRT_DEV V3 normalized(V3 a) { return a / length(a); }                                // vec3.rs:45-47 (three divides)
+// Vec3::normalized (vec3.rs:45-47) is three IEEE divisions by one denominator.  hipcc expands each a / b into v_div_scale x2,
+// v_rcp, two FMAs refining the reciprocal, a multiply, four FMAs and v_div_fixup.  Where v_div_scale does not scale - every
+// operand comfortably inside the exponent range, so that no residual (2^-24 of its operand) goes subnormal - scale and fixup
+// are identities and the refined reciprocal depends on the denominator alone: it is computed once and the three quotients
+// take five operations each (24 instead of 33 instructions, one transcendental instead of three).  Same arithmetic, same
+// bits: tools/micro/div_exact.hip compares the sequence with `/` on 1.4e11 operand pairs with exponents in [-48, 48], edge
+// mantissas included - no mismatch (with exponents up to +-120 it finds 3e-6: the scaling is there for a reason).  Operands
+// outside [2^-40, 2^40] (zeros, subnormals, huge values, infinities) take the plain divisions.
+TRT_DEV float div_by_refined_rcp(float a, float b, float r1) {
+    const float q0 = a * r1;
+    const float e1 = __builtin_fmaf(-b, q0, a);
+    const float q1 = __builtin_fmaf(e1, r1, q0);
+    const float e2 = __builtin_fmaf(-b, q1, a);
+    return __builtin_fmaf(e2, r1, q1);
+}
+TRT_DEV V3 div_shared(V3 a, float b) {
+    const float lo = 9.094947017729282e-13f, hi = 1099511627776.0f;                     // 2^-40, 2^40
+    const float ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z), ab = __builtin_fabsf(b);
+    const float mn = __builtin_fminf(__builtin_fminf(ax, ay), __builtin_fminf(az, ab));
+    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), __builtin_fmaxf(az, ab));
+    if (__builtin_expect(mn >= lo && mx <= hi, 1)) {
+        const float r0 = __builtin_amdgcn_rcpf(b);
+        const float e = __builtin_fmaf(-b, r0, 1.0f);
+        const float r1 = __builtin_fmaf(e, r0, r0);
+        return v3(div_by_refined_rcp(a.x, b, r1), div_by_refined_rcp(a.y, b, r1), div_by_refined_rcp(a.z, b, r1));
+    }
+    return a / b;
+}
+TRT_DEV V3 normalized(V3 a) { return div_shared(a, length(a)); }                         // vec3.rs:45-47 (three divides)
 TRT_DEV V3 cross(V3 a, V3 b) {                                                       // vec3.rs:53-59
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
