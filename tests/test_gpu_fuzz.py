@@ -151,3 +151,16 @@ def test_shared_reciprocal_division_is_ieee_division(tmp_path):
                     os.path.join(root, "tools", "micro", "div_exact.hip")], check=True)
     r = subprocess.run([exe, "512"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
+def test_short_sqrt_is_sqrtf_on_every_float_in_range(tmp_path):
+    """rt_device.h sqrt_in_range (hipcc's sqrtf expansion minus the scaling and the class test) against sqrtf on EVERY float in
+    [2^-80, 2^81): tools/micro/sqrt_exact.hip, exhaustive, exits non-zero on any mismatch."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sqrt_exact")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-o", exe,
+                    os.path.join(root, "tools", "micro", "sqrt_exact.hip")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr

@@ -51,20 +51,35 @@ TRT_DEV float div_by_refined_rcp(float a, float b, float r1) {
     const float e2 = __builtin_fmaf(-b, q1, a);
     return __builtin_fmaf(e2, r1, q1);
 }
-TRT_DEV V3 div_shared(V3 a, float b) {
-    const float lo = 9.094947017729282e-13f, hi = 1099511627776.0f;                     // 2^-40, 2^40
-    const float ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z), ab = __builtin_fabsf(b);
-    const float mn = __builtin_fminf(__builtin_fminf(ax, ay), __builtin_fminf(az, ab));
-    const float mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), __builtin_fmaxf(az, ab));
+// sqrtf likewise: hipcc scales a tiny argument by 2^32, takes v_sqrt_f32, steps the estimate one ulp down / up with an FMA residual
+// each, scales back and passes 0 / inf through by a class test (16 instructions).  For x in [2^-80, 2^81) the scaling and the
+// class test are identities; the 9 instructions that remain give sqrtf's bits for EVERY float in that range
+// (tools/micro/sqrt_exact.hip, exhaustive: 1.35e9 values, 0 mismatches).
+TRT_DEV float sqrt_in_range(float x) {                                                   // requires 2^-80 <= x < 2^81
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float s_dn = __uint_as_float(__float_as_uint(s) - 1u), s_up = __uint_as_float(__float_as_uint(s) + 1u);
+    const float r_dn = __builtin_fmaf(-s_dn, s, x), r_up = __builtin_fmaf(-s_up, s, x);
+    float r = r_dn <= 0.0f ? s_dn : s;
+    r = r_up > 0.0f ? s_up : r;
+    return r;
+}
+// Vec3::normalized (vec3.rs:45-47): a / sqrt(a.a).  Components in [2^-39, 2^39] put the squared length into [2^-78, 2^80) and the
+// length into [2^-39, 2^40): both short forms apply; anything else (a zero component - the 0/0 of vec3extend.rs:32-34 when u3 = 0
+// included -, subnormals, huge values, infinities) takes the plain sqrtf and the three plain divisions.
+TRT_DEV V3 normalized(V3 a) {
+    const float lo = 1.8189894035458565e-12f, hi = 549755813888.0f;                     // 2^-39, 2^39
+    const float ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z);
+    const float mn = __builtin_fminf(__builtin_fminf(ax, ay), az), mx = __builtin_fmaxf(__builtin_fmaxf(ax, ay), az);
+    const float sq = sqlen(a);
     if (__builtin_expect(mn >= lo && mx <= hi, 1)) {
+        const float b = sqrt_in_range(sq);
         const float r0 = __builtin_amdgcn_rcpf(b);
         const float e = __builtin_fmaf(-b, r0, 1.0f);
         const float r1 = __builtin_fmaf(e, r0, r0);
         return v3(div_by_refined_rcp(a.x, b, r1), div_by_refined_rcp(a.y, b, r1), div_by_refined_rcp(a.z, b, r1));
     }
-    return a / b;
+    return a / __builtin_sqrtf(sq);
 }
-TRT_DEV V3 normalized(V3 a) { return div_shared(a, length(a)); }                         // vec3.rs:45-47 (three divides)
 TRT_DEV V3 cross(V3 a, V3 b) {                                                       // vec3.rs:53-59
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
@@ -123,7 +138,8 @@ TRT_DEV float dm_acos(float x) {
     const float ax = __builtin_fabsf(x);
     const bool big = ax > 0.5f;
     const float z = big ? 0.5f * (1.0f - ax) : x * x;
-    const float w = big ? __builtin_sqrtf(z) : x;
+    // z <= 0.25; it is 0 for x = +-1 and tiny next to it: the short sqrt applies from 2^-80 up
+    const float w = big ? (__builtin_expect(z >= 8.271806125530277e-25f, 1) ? sqrt_in_range(z) : __builtin_sqrtf(z)) : x;
     const float r = dm_asin_poly(z) * z * w + w;
     const float two_r = r + r;
     return big ? (x > 0.0f ? two_r : PI_F - two_r) : PIO2_F - r;
