@@ -59,3 +59,16 @@ def test_library_accepts_every_range_bench_produces(bench, trt):
 def test_kernel_source_digest_is_stable(bench):
     assert bench.kernel_source_digest() == bench.kernel_source_digest()
     assert len(bench.kernel_source_digest()) == 16
+
+
+def test_committed_pmc_profile_was_taken_from_these_kernel_sources(bench):
+    """bench.py refuses a PMC profile of other kernel sources (round 1's 100 k-sphere profile had gone stale unnoticed); this
+    fails on CPU as soon as csrc/ changes without tools/pmc_bench.sh + tools/pmc_collect.py having been re-run."""
+    import json
+    table = json.load(open(os.path.join(ROOT, "profiles", "pmc_kernels.json")))
+    entry, stale = bench.pmc_profile("cornell_2048x2048_d50_spp256_streamed")
+    assert entry is not None and not stale, "profiles/pmc_kernels.json is stale: re-profile (tools/pmc_bench.sh, tools/pmc_collect.py)"
+    for key, e in table.items():
+        if not key.startswith("_"):
+            assert e["kernel_source_digest"] == bench.kernel_source_digest(), key
+            assert e["SQ_INSTS_VALU"] > 0 and e["hbm_bytes_per_launch"] > 0 and e["trace_avg_ns"] > 0
