@@ -31,6 +31,8 @@ struct RenderArgs {
     uint32_t lds_leaf_stack;     // streamed backend: keep the postponed leaves in LDS (rt_path.h walk_fast_lds) instead of registers: 0 no, 1 where it costs no occupancy, 2 always
     uint32_t leaf_slots;         // postponed-leaf slots per lane in the walk (rt_path.h walk_fast): 4, 2 or 1
     uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
+    uint32_t stragglers;         // streamed walks of scenes in global memory: a round's walk phase ends once at most this many lanes of the wave still walk
+                                 // (they carry their walk into the next round); 0 = every walk runs to its end (rt_path.h walk_compact)
 };
 
 // trt-rng v1 per-launch key: mix32(seed + golden ratio), evaluated once on the host.

@@ -65,6 +65,11 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     Rng stock_rng;
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
+    // resumable walks (rt_path.h walk_compact) pay for scenes walked from global memory (100 k spheres: 324 trips per round for 222
+    // box steps per ray; +10 %); for LDS-resident trees the carried walk state and the extra rounds cancel the gain (random-spheres +-0)
+    constexpr bool kResumable = !STATS && WALK == WALK_COMPACT;
+    Trav tr{};                                                                    // a walk under way (kResumable only)
+    bool walking = false;
 
     for (;;) {
         // ---- take items ahead: whenever a lane has neither a path nor a stocked ray, every lane without stock takes one ----
@@ -119,13 +124,28 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
         }
         if (has_path) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
-            n_rays++;
-            float t;
-            const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
-            if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
-                float* c = colors + 3ull * out_idx;
-                c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
-                has_path = false;
+            if constexpr (kResumable) {
+                // per-lane tree walk: a lane whose walk is still under way when most of the wave has finished carries it into the
+                // next round (rt_path.h walk_compact) and is not shaded in this one
+                if (!walking) { tr = trav_begin(sc, p.ray, false); walking = true; n_rays++; }
+                const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+                if (closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered)) {
+                    walking = false;
+                    if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
+                        float* c = colors + 3ull * out_idx;
+                        c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                        has_path = false;
+                    }
+                }
+            } else {
+                n_rays++;
+                float t;
+                const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
+                if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
+                    float* c = colors + 3ull * out_idx;
+                    c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                    has_path = false;
+                }
             }
         }
     }
@@ -175,6 +195,11 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
     uint32_t out_idx = 0;
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
+    // resumable walks (rt_path.h walk_compact) pay for scenes walked from global memory (100 k spheres: 324 trips per round for 222
+    // box steps per ray; +10 %); for LDS-resident trees the carried walk state and the extra rounds cancel the gain (random-spheres +-0)
+    constexpr bool kResumable = !STATS && WALK == WALK_COMPACT;
+    Trav tr{};                                                                    // a walk under way (kResumable only)
+    bool walking = false;
 
     TRT_CLK_START(ctr);
     for (;;) {
@@ -240,13 +265,26 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
         TRT_CLK(ctr, 0);
         if (has_path) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
-            n_rays++;
-            float t;
-            const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
-            if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
-                float* c = colors + 3ull * out_idx;
-                c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
-                has_path = false;
+            if constexpr (kResumable) {
+                if (!walking) { tr = trav_begin(sc, p.ray, false); walking = true; n_rays++; }     // see stream_sample_kernel
+                const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
+                if (closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered)) {
+                    walking = false;
+                    if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
+                        float* c = colors + 3ull * out_idx;
+                        c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                        has_path = false;
+                    }
+                }
+            } else {
+                n_rays++;
+                float t;
+                const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
+                if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
+                    float* c = colors + 3ull * out_idx;
+                    c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                    has_path = false;
+                }
             }
         }
         TRT_CLK(ctr, 3);
