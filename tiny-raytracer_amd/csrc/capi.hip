@@ -232,8 +232,6 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     ra.xcd_aware = getenv("TRT_XCD_REMAP") ? 1u : 0u;   // off: contiguous image regions per XCD measured 2x slower (load imbalance)
     ra.stragglers = 12u;                                   // scheduling only: any value renders the same frame
     if (const char* e = getenv("TRT_STRAGGLERS")) ra.stragglers = (uint32_t)atoi(e);
-    ra.flat_stragglers = 4u;
-    if (const char* e = getenv("TRT_FLAT_STRAGGLERS")) ra.flat_stragglers = (uint32_t)atoi(e);
     ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;
 }

@@ -33,7 +33,6 @@ struct RenderArgs {
     uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
     uint32_t stragglers;         // streamed walks of scenes in global memory: a round's walk phase ends once at most this many lanes of the wave still walk
                                  // (they carry their walk into the next round); 0 = every walk runs to its end (rt_path.h walk_compact)
-    uint32_t flat_stragglers;    // the same for the final leaf phase of the lock-step leaf list (rt_path.h walk_flat_resumable)
 };
 
 // trt-rng v1 per-launch key: mix32(seed + golden ratio), evaluated once on the host.

@@ -372,67 +372,6 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
     } while (i < n);
 }
 
-// walk_flat in resumable form (the production Cornell kernel).  The leaf loop's trip count is set by the wave's busiest lane:
-// the average ray tests 1.08 quads, but a ray that starts in a corner stands inside three or four leaf boxes (start = t_min: the
-// re-check can never drop them), so the loop ran 3.4 trips per walk, the later ones for two or three lanes.  Here
-// the FINAL leaf phase of a walk ends as soon as at most `stragglers` lanes still have slots to look at; those lanes keep their
-// slot range [cur, top) (the stack is theirs alone: they take no part in the next box loop) and t_best / prim_best, the other
-// lanes are shaded and start their next walk, and the stragglers' next slots ride along in that walk's leaf trips.  A lane
-// performs exactly the tests it performed before, in the same order with the same t_best; only the round in which a test
-// happens changes.  `fresh`: the lane starts a walk (tr from trav_begin); otherwise it continues one.  Returns true when
-// the lane's walk is complete.  All lanes of the wave that hold a path call this together (the list position is wave-uniform).
-template <int MODE, bool STATS>
-TRT_DEV bool walk_flat_resumable(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf_list, const Ray& ray, Trav& tr, Counters<STATS>& ctr,
-                                 float2* stk, uint32_t slots, bool fresh, float2*& cur, float2*& top, uint32_t stragglers) {
-    const uint32_t n = sc.L.n_leaves;                    // >= 1
-    const uint32_t last = n - 1u;
-    float2* const limit = stk + 64u * (slots - 2u);      // a lane whose top is beyond it cannot hold another pair (slots >= 2)
-    uint32_t i = __builtin_amdgcn_ballot_w64(fresh) != 0ull ? 0u : n;        // wave-uniform list position of the walks that start now
-    if (fresh) { cur = stk; top = stk; }
-    float4 a0 = leaf_list[0], b0 = leaf_list[1];
-    const uint32_t i1 = last < 1u ? last : 1u;
-    float4 a1 = leaf_list[2u * i1], b1 = leaf_list[2u * i1 + 1u];
-    for (;;) {
-        for (; i < n;) {                                 // lock-step box steps, two leaves per trip (see walk_flat)
-            const uint32_t j0 = i + 2u < last ? i + 2u : last, j1 = i + 3u < last ? i + 3u : last;
-            const float4 na0 = leaf_list[2u * j0], nb0 = leaf_list[2u * j0 + 1u], na1 = leaf_list[2u * j1], nb1 = leaf_list[2u * j1 + 1u];
-            float start;
-            if (fresh && slab_fast_entry(a0, b0, ray.o, tr.inv, kTMin, tr.t_best, start)) {
-                *top = make_float2(b0.w, start);
-                top += 64;
-            }
-            if (i + 1u < n) {
-                if (fresh && slab_fast_entry(a1, b1, ray.o, tr.inv, kTMin, tr.t_best, start)) {
-                    *top = make_float2(b1.w, start);
-                    top += 64;
-                }
-            }
-            i += 2u;
-            a0 = na0; b0 = nb0; a1 = na1; b1 = nb1;
-            if (__builtin_amdgcn_ballot_w64(fresh && top > limit) != 0ull) break;       // some lane could not hold another pair
-        }
-        TRT_CLK(ctr, 1);
-        // leaf trips: every lane with slots left looks at its next one
-        for (;;) {
-            const bool pending = cur != top;
-            if (__builtin_amdgcn_ballot_w64(pending) == 0ull) break;
-            if (pending) {
-                const unsigned long long e = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(cur));
-                cur += 64;
-                if (tr.t_best > __uint_as_float((uint32_t)(e >> 32))) trav_leaf<MODE, STATS>(sc, ray, tr, (uint32_t)e, ctr);
-            }
-            if (i >= n) {                                // the list is done: this is the walks' final leaf phase, which may be left
-                const uint32_t left = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(cur != top));
-                if (left <= stragglers) break;
-            }
-        }
-        TRT_CLK(ctr, 2);
-        if (i >= n) break;
-        if (fresh) { cur = stk; top = stk; }              // stack flushed in mid-list (every fresh lane's slots are done): on with the boxes
-    }
-    return cur == top;
-}
-
 // Scenes too large for LDS are bound by the vector-memory front end, not by arithmetic: every box step of every lane is
 // two divergent 16-byte loads (100 k spheres: 9.96 G wave loads per launch, one per 28 cycles per CU, VALU 35 % busy).
 // walk_compact steps a 16-BYTE node instead - the culling tree's boxes rounded OUTWARD to f16, one load per step, half

@@ -200,8 +200,6 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
     constexpr bool kResumable = !STATS && WALK == WALK_COMPACT;
     Trav tr{};                                                                    // a walk under way (kResumable only)
     bool walking = false;
-    constexpr bool kResumableFlat = !STATS && WALK == WALK_FLAT;
-    float2 *stk_cur = nullptr, *stk_top = nullptr;                                // kResumableFlat: the lane's slots still to look at
 
     TRT_CLK_START(ctr);
     for (;;) {
@@ -267,22 +265,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
         TRT_CLK(ctr, 0);
         if (has_path) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
-            if constexpr (kResumableFlat) {
-                // lock-step leaf list with the walks' final leaf phase resumable (rt_path.h walk_flat_resumable)
-                const bool fresh = !walking;
-                if (fresh) { tr = trav_begin(sc, p.ray, false); n_rays++; }
-                bool done;
-                if (__builtin_expect(!tr.ref, 1)) done = walk_flat_resumable<MODE, STATS>(sc, leaf_list, p.ray, tr, ctr, leaf_stack, ra.leaf_slots, fresh, stk_cur, stk_top, ra.flat_stragglers);
-                else { closest_hit_ref<MODE, STATS>(sc, p.ray, tr, ctr); done = true; }
-                walking = !done;
-                if (done) {
-                    if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
-                        float* c = colors + 3ull * out_idx;
-                        c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
-                        has_path = false;
-                    }
-                }
-            } else if constexpr (kResumable) {
+            if constexpr (kResumable) {
                 if (!walking) { tr = trav_begin(sc, p.ray, false); walking = true; n_rays++; }     // see stream_sample_kernel
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
                 if (closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered)) {
