@@ -164,3 +164,29 @@ def test_short_sqrt_is_sqrtf_on_every_float_in_range(tmp_path):
                     os.path.join(root, "tools", "micro", "sqrt_exact.hip")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("n_prims", [400, 560])
+def test_medium_mixed_scenes_in_lds(trt, orc, n_prims):
+    """Mixed spheres and quads with an LDS-resident hot part above 20 KB: the regime of the 768-lane workgroups with an LDS leaf
+    stack (400 primitives: the copy and the stack fit twice per CU) and of their 512-lane fallback with register slots (560)."""
+    desc = random_scene(700 + n_prims, n_prims=n_prims, width=96, height=64)
+    pw, _ = trt.world_from_description(desc)
+    lds = pw.get_bvh().info()["lds_bytes"]
+    assert 20 * 1024 < lds <= 64 * 1024, lds
+    check(trt, orc, desc, spp=3, depth=10)
+
+
+def test_albedo_above_one_takes_the_general_kernels(trt, orc):
+    """SceneLayout::lazy_color is off as soon as a scattering material's albedo exceeds 1 (the attenuation could overflow, and
+    `color += inf * 0` would be NaN in the reference): such scenes run the kernels that carry the colour; same bits as the oracle,
+    and a huge albedo really does produce the reference's NaN / inf pixels."""
+    desc = random_scene(41, n_prims=14)
+    desc["materials"] = [(n, k, (a[0] * 1.6, a[1], a[2]) if k != 3 else a, p) for (n, k, a, p) in desc["materials"]]
+    check(trt, orc, desc, spp=4, depth=12)
+    desc["materials"] = [(n, k, (3.0e30, 2.0e30, 1.0) if k == 0 else a, p) for (n, k, a, p) in desc["materials"]]
+    ow, ocam = orc.world_from_description(desc)
+    cpu, _ = orc.render(ow, ocam, 2, 40, desc["background"], seed=3, nthreads=8)
+    pw, pcam = trt.world_from_description(desc)
+    gpu = trt.Renderer(2, 1, 40, False, desc["background"], seed=3).render(pcam, pw).data
+    assert_bit_equal(gpu, cpu, "overflowing attenuation")
