@@ -162,3 +162,30 @@ def test_kernel_timing_brackets_the_dominant_kernel(trt):
     r.render(pcam, pw)                                              # disabled again: nothing recorded
     trt._lib.check(trt.lib.trt_kernel_timing_end(C.byref(ms), C.byref(n)))
     assert n.value == 0
+
+
+def test_bench_n2_rehearsal_on_one_gpu():
+    """bench.py's N > 1 path (band layout per rank, kernel timing, counter all-reduce, gather + un-interleave, JSON line) with two
+    ranks on this one GPU over gloo (TRT_BENCH_REHEARSAL=1): everything the driver's multi-GPU run does except RCCL itself."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, TRT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--width", "512", "--height", "500", "--spp-per-step", "64", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["unit"] == "Mray/s"
+    assert d["config"]["samples"] == 3 * 64 * 512 * 500                 # both ranks' samples, every pixel once per sample
+    assert d["config"]["image_rows_per_gpu"] == 256                     # 500 rows = 32 bands of 16 (the last one 4 rows): rank 0 owns 16 full bands
+    assert "REHEARSAL" in d["config"]["parallelism"] and d["roofline"]["launches_per_step"] >= 1
