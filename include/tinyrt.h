@@ -189,7 +189,8 @@ int trt_render_device(trt_scene *s, const trt_camera *cam, const trt_render_para
                       uint64_t *d_counters, void *stream);
 
 /* The literal Sampler plug-in form (sampler/mod.rs:10-17): n SamplePoints in, n SampledColors
- * out, HOST buffers.  Point i uses RNG stream (seed, pixel=i, sample=0). */
+ * out, HOST buffers.  Point i uses RNG stream (seed, pixel=i, sample=0).  With `stats` non-NULL the counting kernel runs
+ * (reference-order walk of the reference tree: its counters equal the CPU path's); with NULL the production walk. */
 int trt_sample_batch(trt_scene *s, const trt_sample_point *in, uint32_t n, trt_sampled_color *out,
                      uint32_t max_bounces, trt_vec3 background, uint32_t seed, trt_stats *stats);
 

@@ -209,6 +209,8 @@ def test_sample_batch_liveness_kat_and_parity(trt, orc, golden):
     for depth, bg in ((g["max_bounces"], (0, 0, 0)), (12, (0.7, 0.8, 1.0))):
         gout, gst = trt.sample_batch(pw.get_bvh(), gp, depth, bg, seed=5)
         oout, ost = orc.sample_batch(ow, op, depth, bg, seed=5)
+        fast, _ = trt.sample_batch(pw.get_bvh(), gp, depth, bg, seed=5, collect_stats=False)       # production walk, no counters
+        assert bytes(fast) == bytes(gout)
         assert [gout[i].x for i in range(n)] == list(range(n))            # every sample answered (liveness)
         assert bytes(gout) == bytes(oout)
         for k in STAT_KEYS:

@@ -252,11 +252,12 @@ def tonemap_u8_device(d_accum_ptr, npixels, d_rgb_ptr, gamma=2.2, stream_ptr=0):
                                     C.c_void_p(stream_ptr)))
 
 
-def sample_batch(scene, points, max_bounces, background, seed=1):
-    """trait Sampler in batch form: numpy structured array of SamplePoint -> SampledColor."""
+def sample_batch(scene, points, max_bounces, background, seed=1, collect_stats=True):
+    """trait Sampler in batch form: ctypes array of SamplePoint -> SampledColor.  collect_stats=False runs the production walk
+    (no traversal counters) instead of the counting kernel on the reference tree."""
     n = len(points)
     out = (SampledColor * max(n, 1))()
     st = Stats()
     check(lib.trt_sample_batch(scene._h, C.byref(points) if n else None, n, C.byref(out), max_bounces, _v(background),
-                               seed, C.byref(st)))
+                               seed, C.byref(st) if collect_stats else None))
     return out, st.as_dict()
