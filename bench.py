@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — the reference's headline metric on MI355X: Mray/s (primary + secondary rays) of the path-tracing
 hot path on the Cornell box at 2048x2048, depth 50 (BASELINE.json configs[3]; it fits one GPU), plus the dominant
-kernel's algorithmic-byte rate against the HBM roofline and the CPU oracle timed on this box's host cores.
+kernel's roofline block (VALU lane-slot fraction: the binding resource; physical HBM traffic; SURVEY 8(d)'s algorithmic bytes,
+labelled) and the CPU oracle timed on this box's host cores (all cores and one thread).
 
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -52,6 +53,8 @@ def kernel_source_digest():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "tiny-raytracer_amd", "csrc")
     for name in sorted(os.listdir(d)):
+        if name == "capi.hip":
+            continue                  # host-side C ABI only: no device code, nothing a kernel's counters depend on
         if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
@@ -103,27 +106,39 @@ def usable_cores():
 
 
 def cpu_baseline(trt, desc, depth, budget_s):
-    """The CPU oracle (a port of the reference's CPU path) on a bounded sample of the same workload: whole-image
-    passes of 1 spp, all host cores, until `budget_s` seconds have been spent."""
+    """The CPU oracle (a port of the reference's CPU path) on a bounded sample of the same workload: whole-image passes of 1 spp
+    until the budget is spent - about two thirds of it on all host cores (the headline CPU figure), the rest on ONE thread
+    (the reference's configs[0] is a single-thread run)."""
     from oracle import orc
     import numpy as np
     cores = usable_cores()
     world, cam = orc.world_from_description(desc)
     orc.lib.orc_world_build(world._h)
-    acc = np.zeros((cam.height, cam.width, 3), np.float32)
-    rays = 0
-    spp_done = 0
-    t0 = time.perf_counter()
-    while True:
-        _, st = orc.render(world, cam, 4096, depth, desc["background"], seed=1, nthreads=cores, sample_begin=spp_done,
-                           sample_end=spp_done + 1, accum=acc)
-        rays += st["rays"]
-        spp_done += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or spp_done >= 64:
-            break
-    return {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-            "sample": f"{spp_done} spp of the {cam.width}x{cam.height} depth-{depth} frame ({rays} rays, {dt:.1f} s)"}
+
+    def run(nthreads, seconds, row_end=None):
+        acc = np.zeros((cam.height, cam.width, 3), np.float32)
+        rays = spp_done = 0
+        kw = {} if row_end is None else dict(row_begin=0, row_end=row_end)
+        t0 = time.perf_counter()
+        while True:
+            _, st = orc.render(world, cam, 4096, depth, desc["background"], seed=1, nthreads=nthreads, sample_begin=spp_done,
+                               sample_end=spp_done + 1, accum=acc, **kw)
+            rays += st["rays"]
+            spp_done += 1
+            dt = time.perf_counter() - t0
+            if dt >= seconds or spp_done >= 64:
+                return rays, spp_done, dt
+
+    rays, spp_done, dt = run(cores, budget_s * 2.0 / 3.0)
+    out = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+           "sample": f"{spp_done} spp of the {cam.width}x{cam.height} depth-{depth} frame ({rays} rays, {dt:.1f} s)"}
+    # one thread: a 1-spp pass over the top rows of the frame, sized from the all-core rate to fit the rest of the budget
+    per_thread = rays / dt / max(cores, 1)
+    rows = int(min(cam.height, max(16, (budget_s / 3.0) * per_thread / max(rays / spp_done / cam.height, 1.0))))
+    r1, s1, d1 = run(1, budget_s / 3.0, row_end=rows)
+    out["single_thread"] = {"value": r1 / d1 / 1e6, "unit": "Mray/s", "cores": 1,
+                            "sample": f"{s1} spp of the top {rows} rows ({r1} rays, {d1:.1f} s)"}
+    return out
 
 
 def main():
@@ -252,9 +267,67 @@ def main():
     total_samples = int(counts[0].item())
     launch_ms = [a.elapsed_time(b) for a, b in ev]
 
-    roofline = None
-    if not args.no_roofline_pass:
-        # untimed: the same K launches with the counting kernel variant -> exact algorithmic bytes of those launches
+    # ---- roofline block of the dominant kernel, per rank ----
+    # Live part: the kernel's average launch time from HIP events on its own launch stream (trt_kernel_timing_*), this rank's
+    # rays per launch.  Stored part: VALU instruction and HBM byte counts PER RAY from the rocprofv3 PMC passes kept under
+    # profiles/ (tools/pmc_bench.sh; counters need their own runs), scaled by this rank's rays - so the block exists at any N.
+    # Nothing here can end the run: what does not add up goes into roofline["warnings"].
+    warnings = []
+    launches_per_step = 1
+    if args.backend == "streamed":
+        chunk = trt.lib.trt_streamed_chunk_spp(W, max(rows_local, 1))
+        launches_per_step = (S + chunk - 1) // chunk
+    if rows_local == 0:
+        launches_per_step = 0
+    n_launch = int(k_n.value)
+    if n_launch != launches_per_step * args.steps:
+        warnings.append(f"timed {n_launch} dominant-kernel launches, expected {launches_per_step * args.steps}")
+    avg_ms = k_ms.value / n_launch if n_launch else None
+    my_rays = int(ctr[1].item())
+    rays_per_launch = my_rays / n_launch if n_launch else 0.0
+    key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}"
+    prof, stale = pmc_profile(key)
+    roofline = {"bound": "valu", "kernel": kernel_name, "achieved": None, "peak": round(VALU_PEAK_GINST * 64.0 / 1e3, 2),
+                "unit": "T f32 lane-instructions/s (VALU wave-instructions x active lanes)", "frac": None, "traffic": None,
+                "frac_is": "lane-slot fraction: VALU lane-instructions per second / (1024 SIMDs x 2.4 GHz / 2 cycles x 64 lanes); "
+                           "instruction counts per ray from a stored PMC profile of the same kernel sources, launch time measured live",
+                "avg_launch_ms": round(avg_ms, 4) if avg_ms else None, "launches_per_step": launches_per_step, "launches_timed": n_launch,
+                "rays_per_launch": int(rays_per_launch), "step_ms_by_events": round(sum(launch_ms) / len(launch_ms), 4),
+                "pmc_key": key, "pmc_stale": stale, "rank": rank}
+    if prof is not None and not stale and avg_ms and rays_per_launch > 0:
+        prof_rays = prof.get("rays_per_launch")
+        if not prof_rays:
+            if world_size == 1:
+                prof_rays = rays_per_launch              # entries older than the field: same workload, same rays
+            else:
+                warnings.append("PMC entry has no rays_per_launch: cannot scale it to this rank's share")
+        if prof_rays:
+            scale = rays_per_launch / prof_rays
+            insts = prof["SQ_INSTS_VALU"] * scale
+            lanes = prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_INSTS_VALU"] if prof.get("SQ_THREAD_CYCLES_VALU") else None   # active lanes per VALU instruction
+            hbm = prof["hbm_bytes_per_launch"] * scale
+            issue_rate = insts / (avg_ms * 1e-3) / 1e9                                    # G wave-instructions / s
+            issue_frac = issue_rate / VALU_PEAK_GINST
+            roofline.update({
+                "issue_frac": round(issue_frac, 4), "issue_achieved_Ginst_s": round(issue_rate, 1), "issue_peak_Ginst_s": round(VALU_PEAK_GINST, 1),
+                "valu_wave_insts_per_launch": int(insts), "valu_wave_insts_per_ray": round(prof["SQ_INSTS_VALU"] / prof_rays, 2) if prof_rays else None,
+                "cycles_per_valu_inst_per_simd": round(avg_ms * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
+                "peak_cycles_per_valu_inst_per_simd": 2.0, "mean_active_lanes": round(lanes, 1) if lanes else None,
+                "salu_insts_per_launch": int(prof.get("SQ_INSTS_SALU", 0) * scale), "traffic": int(hbm),
+                "hbm_physical_GBps": round(hbm / (avg_ms * 1e-3) / 1e9, 1), "hbm_physical_frac": round(hbm / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "pmc_source": prof.get("source")})
+            if lanes:
+                roofline["achieved"] = round(issue_rate * lanes / 1e3, 2)
+                roofline["frac"] = round(issue_frac * lanes / 64.0, 4)
+                roofline["lane_slot_frac"] = roofline["frac"]
+            if issue_frac > 1.0 or roofline["hbm_physical_frac"] > 1.0:
+                warnings.append("a fraction above 1: the stored PMC profile does not describe this run (other box clock, other build?)")
+    elif prof is None:
+        warnings.append("no PMC profile for this workload under profiles/pmc_kernels.json: frac is null")
+    elif stale:
+        warnings.append("the PMC profile was taken from other kernel sources (pmc_stale): frac is null until tools/pmc_bench.sh is re-run")
+    if not args.no_roofline_pass and rows_local > 0:
+        # untimed: the same K launches with the counting kernel variant -> exact algorithmic bytes of those launches (SURVEY 8(d))
         sctr = torch.zeros(16, dtype=torch.int64, device=dev)
         scratch = torch.zeros_like(acc)
         for k in range(args.steps):
@@ -262,52 +335,32 @@ def main():
         torch.cuda.synchronize()
         c = dict(zip(("samples", "rays", "node_tests", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"),
                      [int(v) for v in sctr[:7].tolist()]))
-        assert c["rays"] == int(ctr[1].item()), "counting variant traced a different number of rays"
-        # the streamed backend splits a step into chunks: one dominant-kernel launch (+ one small fold launch) per chunk
-        launches_per_step = 1
-        if args.backend == "streamed":
-            chunk = trt.lib.trt_streamed_chunk_spp(W, rows_local)
-            launches_per_step = (S + chunk - 1) // chunk
-        if rows_local == 0:
-            launches_per_step = 0
-        assert k_n.value == launches_per_step * args.steps, "one timed dominant-kernel launch per chunk"
-        bytes_per_launch = (algorithmic_bytes(c, 0) / args.steps + 12 * rows_local * W) / max(launches_per_step, 1)
-        avg_ms = k_ms.value / max(k_n.value, 1)                 # the dominant kernel alone (a step also holds the small fold launches)
-        achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-        algorithmic = {"bytes_per_launch": int(bytes_per_launch), "GBps": round(achieved, 2),
-                       "ratio_to_hbm_peak": round(achieved / HBM_PEAK_GBPS, 5),
-                       "bytes_per_ray": round(algorithmic_bytes(c, 0) / max(c["rays"], 1), 2),
-                       "note": "SURVEY 8(d): bytes the reference-order traversal would read per launch / launch time. NOT a "
-                               "physical fraction: the scene is served from LDS/SGPRs/L2, so it may exceed 1"}
-        # The binding resource is VALU issue: instruction counts and physical HBM bytes per launch of the
-        # dominant kernel come from the rocprofv3 PMC passes kept under profiles/ (tools/pmc_bench.sh), the launch time
-        # is the one measured live above.  A profile of other kernel sources is refused.
-        key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}"
-        prof, stale = pmc_profile(key)
-        roofline = {"bound": "valu", "kernel": kernel_name, "achieved": None, "peak": round(VALU_PEAK_GINST, 1),
-                    "unit": "G wave64 VALU instructions/s", "frac": None, "traffic": None,
-                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
-                    "step_ms_by_events": round(sum(launch_ms) / len(launch_ms), 4),
-                    "rays_per_sample": round(c["rays"] / max(c["samples"], 1), 3),
-                    "pmc_key": key, "pmc_stale": stale, "algorithmic": algorithmic}
-        if prof is not None and not stale and world_size == 1:
-            insts = prof["SQ_INSTS_VALU"]
-            valu_rate = insts / (avg_ms * 1e-3) / 1e9
-            lanes = prof["SQ_THREAD_CYCLES_VALU"] / insts if prof.get("SQ_THREAD_CYCLES_VALU") else None      # active lanes per VALU instruction
-            hbm = prof["hbm_bytes_per_launch"]
-            roofline.update({
-                "achieved": round(valu_rate, 1), "frac": round(valu_rate / VALU_PEAK_GINST, 4), "traffic": int(hbm),
-                "valu_wave_insts_per_launch": int(insts),
-                "valu_wave_insts_per_ray": round(insts * launches_per_step * args.steps / max(total_rays, 1), 2),
-                "cycles_per_valu_inst_per_simd": round(avg_ms * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
-                "peak_cycles_per_valu_inst_per_simd": 2.0,
-                "mean_active_lanes": round(lanes, 1) if lanes else None,
-                "lane_slot_frac": round(valu_rate / VALU_PEAK_GINST * lanes / 64.0, 4) if lanes else None,
-                "salu_insts_per_launch": int(prof.get("SQ_INSTS_SALU", 0)),
-                "hbm_physical_GBps": round(hbm / (avg_ms * 1e-3) / 1e9, 1),
-                "hbm_physical_frac": round(hbm / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "pmc_source": prof.get("source")})
-            assert roofline["frac"] <= 1.0 and roofline["hbm_physical_frac"] <= 1.0, "a roofline fraction above 1 is a bug"
+        if c["rays"] != my_rays:
+            warnings.append(f"counting variant traced {c['rays']} rays, the timed launches {my_rays}")
+        roofline["rays_per_sample"] = round(c["rays"] / max(c["samples"], 1), 3)
+        if avg_ms and n_launch:
+            bytes_per_launch = (algorithmic_bytes(c, 0) + 12 * rows_local * W * args.steps) / n_launch
+            gbps = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+            roofline["algorithmic"] = {
+                "bytes_per_launch": int(bytes_per_launch), "GBps": round(gbps, 2), "ratio_to_hbm_peak": round(gbps / HBM_PEAK_GBPS, 5),
+                "bytes_per_ray": round(algorithmic_bytes(c, 0) / max(c["rays"], 1), 2),
+                "note": "SURVEY 8(d): bytes the reference-order traversal would read per launch / launch time.  NOT a physical "
+                        "fraction and not a roofline for this path: the scene is served from SGPRs / LDS / L2, so it exceeds 1 "
+                        "(DESIGN.md section 8); the physical HBM traffic is `traffic`"}
+    roofline["warnings"] = warnings
+    # per-rank summary on rank 0 (N > 1): launch time and rays of every rank
+    per_rank = None
+    if world_size > 1:
+        mine = torch.tensor([avg_ms or 0.0, float(n_launch), float(my_rays), float(rows_local), roofline["frac"] or 0.0], dtype=torch.float64, device=dev)
+        table = [torch.zeros_like(mine) for _ in range(world_size)]
+        if rehearsal:
+            host = [t.cpu() for t in table]
+            dist.all_gather(host, mine.cpu())
+            table = host
+        else:
+            dist.all_gather(table, mine)
+        per_rank = [{"rank": r, "avg_launch_ms": round(float(t[0]), 4), "launches": int(t[1]), "rays": int(t[2]), "image_rows": int(t[3]),
+                     "frac": round(float(t[4]), 4) if float(t[4]) > 0 else None} for r, t in enumerate(table)]
 
     cpu = None
     if rank == 0 and world_size == 1 and args.cpu_seconds > 0:
@@ -328,6 +381,8 @@ def main():
                                       if world_size > 1 else "single GPU"},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if per_rank is not None:
+            out["roofline_per_rank"] = per_rank
         print(json.dumps(out), flush=True)
     if world_size > 1:
         dist.barrier()

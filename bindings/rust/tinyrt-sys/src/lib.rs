@@ -1,11 +1,11 @@
-//! Raw declarations of `include/tinyrt.h` (ABI version 1).  Field order, scalar types and function parameter lists are
+//! Raw declarations of `include/tinyrt.h` (ABI version 2).  Field order, scalar types and function parameter lists are
 //! checked against the header by tests/test_rust_bindings.py; the crate itself has never been compiled (no Rust
 //! toolchain in the build image).
 #![allow(non_camel_case_types)]
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const TRT_ABI_VERSION: u32 = 1;
+pub const TRT_ABI_VERSION: u32 = 2;
 
 // enum trt_status
 pub const TRT_OK: c_int = 0;
@@ -114,6 +114,46 @@ pub struct trt_render_params {
 
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default, PartialEq)]
+pub struct trt_band_copy {
+    pub rows_local: u32,
+    pub full_bands: u32,
+    pub tail_rows: u32,
+    pub reserved: u32,
+    pub band_bytes: u64,
+    pub local_pitch: u64,
+    pub frame_pitch: u64,
+    pub frame_offset: u64,
+    pub tail_bytes: u64,
+    pub tail_local_offset: u64,
+    pub tail_frame_offset: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq)]
+pub struct trt_launch_plan {
+    pub scene_mode: u32,
+    pub threads_per_workgroup: u32,
+    pub waves_per_simd: u32,
+    pub workgroups_per_cu: u32,
+    pub lds_bytes: u32,
+    pub scene_lds_bytes: u32,
+    pub leaf_slots: u32,
+    pub lds_leaf_stack: u32,
+    pub ray_pool: u32,
+    pub walk: u32,
+    pub specialised: u32,
+    pub has_kernel: u32,
+    pub kernel_waves_per_simd: u32,
+    pub kernel_threads: u32,
+    pub kernel_walk: u32,
+    pub kernel_ray_pool: u32,
+    pub kernel_counting: u32,
+    pub chunk_spp: u32,
+    pub workspace_bytes: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq)]
 pub struct trt_stats {
     pub samples: u64,
     pub rays: u64,
@@ -148,6 +188,7 @@ extern "C" {
 
     pub fn trt_scene_create(w: *const trt_world, out: *mut *mut trt_scene) -> c_int;
     pub fn trt_scene_destroy(s: *mut trt_scene);
+    pub fn trt_scene_trim(s: *mut trt_scene) -> c_int;
     pub fn trt_scene_get_info(s: *const trt_scene, out: *mut trt_scene_info) -> c_int;
     pub fn trt_scene_get_nodes(s: *const trt_scene, bbox6: *mut f32, prim: *mut i32, skip: *mut i32, cap: u32) -> c_int;
     pub fn trt_scene_get_cull_nodes(s: *const trt_scene, bbox6: *mut f32, prim: *mut i32, skip: *mut i32, cap: u32) -> c_int;
@@ -163,6 +204,9 @@ extern "C" {
     pub fn trt_render_multi_device(s: *mut trt_scene, cam: *const trt_camera, p: *const trt_render_params,
                                    devices: *const c_int, ndev: u32, d_accum: *mut f32, stats: *mut trt_stats) -> c_int;
     pub fn trt_band_rows_local(height: u32, ndev: u32, rank: u32, rows_local: *mut u32) -> c_int;
+    pub fn trt_band_copy_plan(width: u32, height: u32, ndev: u32, rank: u32, out: *mut trt_band_copy) -> c_int;
+    pub fn trt_streamed_launch_plan(s: *const trt_scene, cam: *const trt_camera, p: *const trt_render_params,
+                                    out: *mut trt_launch_plan) -> c_int;
     pub fn trt_render_device(s: *mut trt_scene, cam: *const trt_camera, p: *const trt_render_params, d_accum: *mut f32,
                              d_counters: *mut u64, stream: *mut c_void) -> c_int;
     pub fn trt_sample_batch(s: *mut trt_scene, input: *const trt_sample_point, n: u32, out: *mut trt_sampled_color,

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define TRT_ABI_VERSION 1
+#define TRT_ABI_VERSION 2   /* 2 (round 3): + trt_scene_trim, trt_streamed_launch_plan, trt_band_copy_plan */
 
 enum trt_status {
     TRT_OK = 0,
@@ -81,7 +81,14 @@ int trt_world_num_materials(const trt_world *w);
  * on first render, so a scene can be compiled and inspected on a machine without a GPU. */
 typedef struct trt_scene trt_scene;
 int trt_scene_create(const trt_world *w, trt_scene **out);
+/* Must not run while another host thread is inside a render call on this scene; renders enqueued with trt_render_device
+ * that still run on the device are waited for. */
 void trt_scene_destroy(trt_scene *s);
+/* The scene handle caches device resources per device: the uploaded scene, render scratch ("workspaces": up to 8 per device,
+ * e.g. 3.2 GB each at 2048x2048) and, for the blocking entry points, contexts (stream, events, counters, a device frame).
+ * Idle scratch beyond 8 GiB per device (environment TRT_SCRATCH_CAP_MB) is freed when a render ends; this call frees ALL idle
+ * scratch now (whatever running renders own is skipped).  The uploaded scene stays. */
+int trt_scene_trim(trt_scene *s);
 
 typedef struct {
     uint32_t num_nodes, num_spheres, num_quads, num_materials;
@@ -160,8 +167,9 @@ int trt_render(trt_scene *s, const trt_camera *cam, const trt_render_params *p, 
 
 /* Renderer::render over several GPUs of one node: still ONE call that returns the whole frame (renderer.rs:37-79;
  * src/main.rs:19).  The scene is replicated, the image is cut into bands of 16 rows dealt round-robin over the shards
- * (band b -> shard b % ndev), one host thread per shard drives its device, and each finished band is copied straight to its
- * place in `accum` (HOST buffer, height*width*3 f32; read first when p->accumulate is set).  The frame is bit-identical for
+ * (band b -> shard b % ndev), one host thread per shard drives its device, and each shard's bands are copied straight to their
+ * place in `accum` (HOST buffer, height*width*3 f32; read first when p->accumulate is set) with one strided 2-D copy
+ * (trt_band_copy_plan).  The frame is bit-identical for
  * every ndev and equals trt_render's: the RNG is keyed by the image pixel and every pixel is folded in sample order.
  * `devices`: ndev device ordinals (a device may appear more than once: its shards then run concurrently on it), or NULL
  * for 0..ndev-1; ndev == 0 means every visible device.  p->band_rows must be 0.  stats (may be NULL): counters summed over
@@ -169,12 +177,23 @@ int trt_render(trt_scene *s, const trt_camera *cam, const trt_render_params *p, 
 int trt_render_multi(trt_scene *s, const trt_camera *cam, const trt_render_params *p, const int *devices, uint32_t ndev,
                      float *accum, trt_stats *stats);
 /* The same with the frame gathered into HBM: `d_accum` is a buffer of height*width*3 f32 on devices[0] (device 0 when
- * `devices` is NULL); every shard sends its bands there with one peer copy per band (xGMI between the GPUs of a node).
+ * `devices` is NULL); every shard sends its bands there with one strided 2-D device-to-device copy (xGMI between the GPUs of a node; staged
+ * through the host per band where two devices have no peer access).
  * Synchronous: the frame is complete when the call returns. */
 int trt_render_multi_device(trt_scene *s, const trt_camera *cam, const trt_render_params *p, const int *devices,
                             uint32_t ndev, float *d_accum, trt_stats *stats);
 /* Rows of an image of `height` rows that shard `rank` of `ndev` owns under that band layout (host arithmetic only). */
 int trt_band_rows_local(uint32_t height, uint32_t ndev, uint32_t rank, uint32_t *rows_local);
+/* The gather of one shard as trt_render_multi[_device] performs it (host arithmetic only; bytes).  A shard keeps its rows
+ * contiguous; in the frame its k-th band starts at row (k * ndev + rank) * 16, i.e. at a constant pitch: ONE strided 2-D copy
+ * (`full_bands` rows of `band_bytes`, source pitch `local_pitch`, destination `frame_offset` + k * `frame_pitch`) moves all
+ * full bands, one 1-D copy of `tail_bytes` the ragged last band if the shard owns it. */
+typedef struct {
+    uint32_t rows_local, full_bands, tail_rows, reserved;
+    uint64_t band_bytes, local_pitch, frame_pitch, frame_offset;
+    uint64_t tail_bytes, tail_local_offset, tail_frame_offset;
+} trt_band_copy;
+int trt_band_copy_plan(uint32_t width, uint32_t height, uint32_t ndev, uint32_t rank, trt_band_copy *out);
 
 /* Same, on buffers already resident in HBM.  `d_accum`: device pointer, rows*width*3 f32.
  * `d_counters`: device pointer to 16 uint64 (zeroed by the caller; [0..6] = trt_stats' first seven
@@ -184,7 +203,7 @@ int trt_band_rows_local(uint32_t height, uint32_t ndev, uint32_t rank, uint32_t 
  * Concurrency (all render entry points): a scene is immutable once created and may be rendered by several host threads
  * and on several streams at the same time; every render takes private device scratch from a pool on the scene handle
  * (at most 8 scratch buffers per device: further concurrent renders queue behind running ones on the device).
- * trt_scene_destroy must not run while a render of that scene is still being enqueued. */
+ * trt_scene_destroy must not run while a host thread is inside a render call of that scene. */
 int trt_render_device(trt_scene *s, const trt_camera *cam, const trt_render_params *p, float *d_accum,
                       uint64_t *d_counters, void *stream);
 
@@ -199,9 +218,28 @@ int trt_sample_batch(trt_scene *s, const trt_sample_point *in, uint32_t n, trt_s
 int trt_tonemap_u8(const float *accum, uint32_t npixels, float gamma, uint8_t *rgb);
 
 /* The same on buffers resident in HBM (device pointers), asynchronous on `stream` (a hipStream_t, NULL = default): the
- * frame never has to leave the GPU as f32.  c^(1/gamma) is evaluated in f64 on the device; against the host form
- * (libm powf) a channel may differ by one least-significant bit where powf is not correctly rounded. */
+ * frame never has to leave the GPU as f32.  Host form and device kernel evaluate c^(1/gamma) with the same function (trt-math v1
+ * powf, csrc/trt_pow.h): their u8 frames are equal byte for byte.  Against the reference, which calls the platform's libm powf
+ * (utils/image.rs:94-96), a channel may differ by one least-significant bit where that powf is not correctly rounded. */
 int trt_tonemap_u8_device(const float *d_accum, uint32_t npixels, float gamma, uint8_t *d_rgb, void *stream);
+
+/* How the streamed backend launches a render of this scene with these settings (host arithmetic only: works without a GPU).
+ * The kernels' view of their dynamic LDS - scene copy | postponed-leaf stack (threads x leaf_slots x 8 B) | ray pool (36 B per
+ * lane) - is decided in ONE place (streamed.hip streamed_launch_plan) and reported here, so that its invariants can be checked
+ * for every scene size and every tuning knob without a device (tests/test_host_boundary.py). */
+typedef struct {
+    uint32_t scene_mode;              /* 0 scene read from global memory, 1 whole hot scene copied into LDS, 2 top levels in LDS */
+    uint32_t threads_per_workgroup, waves_per_simd, workgroups_per_cu;
+    uint32_t lds_bytes, scene_lds_bytes;      /* dynamic LDS per workgroup; the scene copy's share */
+    uint32_t leaf_slots, lds_leaf_stack, ray_pool;
+    uint32_t walk;                    /* 1 tree walk with LDS leaf stack, 2 lock-step leaf list, 3 16-byte nodes, 5 tree walk with register slots */
+    uint32_t specialised;             /* 1: a kernel with the walk fixed at compile time */
+    uint32_t has_kernel;              /* 0 would be a bug: no instantiation for the plan (the launch then fails, it never falls back) */
+    uint32_t kernel_waves_per_simd, kernel_threads, kernel_walk /* 0 = chosen at run time */, kernel_ray_pool, kernel_counting;
+    uint32_t chunk_spp;               /* = trt_streamed_chunk_spp(width, rows) */
+    uint64_t workspace_bytes;         /* device scratch one render of this size takes from the scene's pool */
+} trt_launch_plan;
+int trt_streamed_launch_plan(const trt_scene *s, const trt_camera *cam, const trt_render_params *p, trt_launch_plan *out);
 
 /* Samples per pixel the streamed backend traces per kernel launch for an image of this size (it splits longer sample
  * ranges into such chunks; one chunk = one `trt::stream_sample_kernel` launch + one fold launch). */
@@ -209,7 +247,8 @@ uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows);
 
 /* Measurement aid: between _begin and _end every launch of a render's dominant kernel (streamed backend: the sample
  * kernel, not the fold) is bracketed by HIP events on the stream it is launched on; _end waits for them and returns the
- * summed device time and the number of launches.  Process-wide; meant for one rendering thread at a time. */
+ * summed device time and the number of launches.  Process-wide switch; a launch's two events are paired on the host thread
+ * that makes the launch, so renders on several threads, streams or devices (trt_render_multi) never mix their brackets. */
 int trt_kernel_timing_begin(void);
 int trt_kernel_timing_end(double *total_ms, uint32_t *launches);
 

@@ -1,0 +1,89 @@
+"""BASELINE configs[1] and configs[2] at FULL size on the DEFAULT backend: Cornell 800x800 and the random-spheres
+scene at 1920x1080, depth 50, through the streamed backend's production plans (lock-step leaf list + ray pool; 768-lane
+workgroups with the LDS leaf stack) - the shapes `bench.py --scene ...` measures.  In the form of tests/test_gpu_cfg5.py:
+
+ * oracle parity, bit for bit, on the whole frame at a few spp (the oracle needs a second or two) and on 16-row bands rendered
+   AS bands (top / middle / ragged bottom), with the counting kernel's counters equal to the oracle's;
+ * full-frame properties at the config's depth: accounting (every pixel gets every sample exactly once), determinism,
+   progressive passes == one pass, multi-shard render == one render, and the plan that ran is the one the bench measures."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DEPTH = 50
+CASES = {
+    "cfg2_cornell_800": dict(scene="cornell", w=800, h=800, plan=dict(walk=2, threads_per_workgroup=256, ray_pool=1, specialised=1)),
+    "cfg3_random_spheres_1080p": dict(scene="random_spheres", w=1920, h=1080, plan=dict(walk=1, threads_per_workgroup=768, ray_pool=0, specialised=1)),
+}
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def describe(trt, case):
+    c = CASES[case]
+    return getattr(trt.scenes, c["scene"])(c["w"], c["h"]), c
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_at_size_full_frame_bit_exact_against_the_oracle(trt, orc, case):
+    desc, c = describe(trt, case)
+    spp = 2
+    ow, ocam = orc.world_from_description(desc)
+    cpu, cst = orc.render(ow, ocam, spp, DEPTH, desc["background"], seed=5, nthreads=16)
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(spp, 1, DEPTH, False, desc["background"], seed=5)            # backend: the library's default
+    plan = trt._lib.LaunchPlan()
+    trt._lib.check(trt.lib.trt_streamed_launch_plan(pw.get_bvh()._h, C.byref(pcam.pod), C.byref(r.params()), C.byref(plan)))
+    for k, v in c["plan"].items():
+        assert getattr(plan, k) == v, (case, k, plan.as_dict())                 # the production plan bench.py measures
+    got = r.render(pcam, pw).data
+    assert r.last_stats["samples"] == c["w"] * c["h"] * spp and r.last_stats["rays"] == cst["rays"]
+    assert np.array_equal(bits(got), bits(cpu)), f"{case}: default backend differs from the oracle on the full frame"
+    counted = r.render(pcam, pw, collect_stats=True)
+    assert np.array_equal(bits(counted.data), bits(cpu))
+    for k in ("samples", "rays", "node_tests", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
+        assert r.last_stats[k] == cst[k], (case, k)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_at_size_bands_rendered_as_bands(trt, orc, case):
+    desc, c = describe(trt, case)
+    pw, pcam = trt.world_from_description(desc)
+    ow, ocam = orc.world_from_description(desc)
+    r = trt.Renderer(4, 1, DEPTH, False, desc["background"], seed=11)
+    n_bands = (c["h"] + 15) // 16                                               # 1080 rows: 67 full bands + one of 8 rows
+    for band in (0, n_bands // 2, n_bands - 1):
+        y0, y1 = 16 * band, min(16 * band + 16, c["h"])
+        cpu, cst = orc.render(ow, ocam, 4, DEPTH, desc["background"], seed=11, nthreads=16, row_begin=y0, row_end=y1)
+        got = r.render(pcam, pw, band_rows=16, band_stride=n_bands, band_offset=band, rows_local=y1 - y0)
+        assert np.array_equal(bits(got.data), bits(cpu[y0:y1])), (case, band)
+        assert r.last_stats["rays"] == cst["rays"], (case, band)
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_at_size_frame_properties(trt, case):
+    desc, c = describe(trt, case)
+    W, H, spp = c["w"], c["h"], 16
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(spp, 1, DEPTH, False, desc["background"], seed=3)
+    whole = r.render(pcam, pw).data
+    st = dict(r.last_stats)
+    assert st["samples"] == W * H * spp and spp * W * H <= st["rays"] <= DEPTH * spp * W * H      # accounting
+    assert np.isfinite(whole).all() and whole.min() >= 0.0 and whole.mean() > 0.01
+    again = r.render(pcam, pw).data                                                              # determinism
+    assert np.array_equal(bits(again), bits(whole)) and r.last_stats["rays"] == st["rays"]
+    acc = np.zeros((H, W, 3), np.float32)                                                        # progressive == one pass
+    r.render(pcam, pw, accum=acc, sample_begin=0, sample_end=5)
+    r.render(pcam, pw, accum=acc, sample_begin=5, sample_end=6, accumulate=1)
+    r.render(pcam, pw, accum=acc, sample_begin=6, sample_end=16, accumulate=1)
+    assert np.array_equal(bits(acc), bits(whole))
+    for devices in ([0, 0], [0, 0, 0, 0, 0]):                                                    # multi-shard == one render
+        sharded = r.render_multi(pcam, pw, devices=devices)
+        assert np.array_equal(bits(sharded.data), bits(whole)) and r.last_stats["rays"] == st["rays"], devices
+    mega = trt.Renderer(spp, 1, DEPTH, False, desc["background"], seed=3, backend=trt.BACKEND_MEGAKERNEL).render(pcam, pw).data
+    assert np.array_equal(bits(mega), bits(whole))                                               # another backend, same frame

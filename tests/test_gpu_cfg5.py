@@ -5,8 +5,7 @@
    host cores), bit for bit, plus the ray count;
  * oracle parity on 16-row bands at 2 spp rendered AS bands (trt_render_params band layout), top / middle / bottom;
  * the counting kernel's node / sphere / shade counters against the oracle's on those bands (reference-order walk);
- * default walk (16-byte f16 culling nodes) vs the opt-in near-first walk (TRT_ORDERED_WALK=1) vs 32-byte nodes: frames
-   and ray counts identical on the full frame;
+ * default walk (16-byte f16 culling nodes) vs 32-byte nodes: frames and ray counts identical on the full frame;
  * size-independent properties at 4 spp: progressive passes == one pass; multi-shard render == one render."""
 import numpy as np
 import pytest
@@ -30,9 +29,8 @@ def test_cfg5_full_frame_bit_exact_against_the_oracle(trt, orc, cfg5, monkeypatc
     ow, ocam = orc.world_from_description(desc)
     cpu, cst = orc.render(ow, ocam, 1, DEPTH, desc["background"], seed=1, nthreads=16)
     frames = {}
-    for name, env in (("default", {}), ("ordered", {"TRT_ORDERED_WALK": "1"}), ("nodes32", {"TRT_COMPACT_NODES": "0"})):
-        for k in ("TRT_ORDERED_WALK", "TRT_COMPACT_NODES"):
-            monkeypatch.delenv(k, raising=False)
+    for name, env in (("default", {}), ("nodes32", {"TRT_COMPACT_NODES": "0"})):
+        monkeypatch.delenv("TRT_COMPACT_NODES", raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)                                 # read when the scene is compiled
         pw, pcam = trt.world_from_description(desc)

@@ -104,17 +104,13 @@ def test_walk_schedules_agree_on_many_rays(trt, monkeypatch, seed):
 
 @pytest.mark.parametrize("spheres_only", [False, True])
 def test_global_memory_walks_agree_on_many_rays(trt, monkeypatch, spheres_only):
-    """Scenes walked from global memory (hot part > 64 KB), ~10^8 rays: the near-first walk through the free-order tree
-    (sphere-only scenes; a scene with quads ignores the request), the fixed-order 16-byte-node walk (f16 boxes, exact
-    leaf boxes re-tested), the 32-byte-node walk, the plain one-slot walk and the megakernel - frames and ray counts;
-    primitive-test counters too for the fixed-order walks (the near-first walk tests other primitives on its way to
-    the same answer)."""
+    """Scenes walked from global memory (hot part > 64 KB), ~10^8 rays: the 16-byte-node walk (f16 boxes, exact leaf boxes
+    re-tested), the 32-byte-node walk, the plain one-slot walk and the megakernel - frames, ray counts and primitive-test
+    counters."""
     desc = random_scene(500 + int(spheres_only), n_prims=3000, width=1280, height=800, p_sphere=1.0 if spheres_only else 0.5)
     ref_img = ref_stats = None
-    for backend, compact, ordered, slots in ((3, "0", "0", "1"), (3, "1", "1", None), (3, "1", "0", None), (3, "0", "0", None),
-                                            (3, "1", "1", "2"), (3, "1", "0", "2"), (0, "0", "0", None)):
-        monkeypatch.setenv("TRT_COMPACT_NODES", compact)                            # both read when the scene is compiled
-        monkeypatch.setenv("TRT_ORDERED_WALK", ordered)
+    for backend, compact, slots in ((3, "0", "1"), (3, "1", None), (3, "0", None), (3, "1", "2"), (0, "0", None)):
+        monkeypatch.setenv("TRT_COMPACT_NODES", compact)                            # read when the scene is compiled
         if slots is None:
             monkeypatch.delenv("TRT_LEAF_SLOTS", raising=False)
         else:
@@ -128,15 +124,11 @@ def test_global_memory_walks_agree_on_many_rays(trt, monkeypatch, spheres_only):
         plain = r.render(pcam, pw)                                                   # production kernel
         if ref_img is None:
             ref_img, ref_stats = img.data.copy(), st
-        tag = f"{desc['name']} backend {backend} compact {compact} ordered {ordered} slots {slots}"
+        tag = f"{desc['name']} backend {backend} compact {compact} slots {slots}"
         assert_bit_equal(img.data, ref_img, tag + " (counting)")
         assert_bit_equal(plain.data, ref_img, tag)
-        near_first = ordered == "1" and spheres_only and backend == 3
-        keys = ("samples", "rays", "shades") if near_first else ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades")
-        for k in keys:
+        for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
             assert st[k] == ref_stats[k], (tag, k)
-        if near_first:
-            assert st["node_tests"] < 0.7 * ref_stats["node_tests"], tag              # the point of it: far fewer box tests
 
 
 def test_shared_reciprocal_division_is_ieee_division(tmp_path):

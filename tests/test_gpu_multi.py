@@ -89,18 +89,18 @@ def test_render_multi_rejects_bad_arguments(trt):
 def test_concurrent_renders_of_one_scene_equal_serial_ones(trt, backend):
     """Round 1 cached ONE device workspace (radiance records + batch counter) on the scene handle, shared by every render:
     two renders of one scene at the same time overwrote each other's records.  Now every render owns its scratch until
-    its last kernel has run.  Four host threads render the same scene handle at once, each with its own seed and sample
+    its last kernel has run.  Six host threads render the same scene handle at once, each with its own seed and sample
     count (ctypes releases the GIL during the call; trt_render uses a stream of its own); every frame must equal the one
     rendered alone."""
     be = {"streamed": trt.BACKEND_STREAMED, "wavefront": trt.BACKEND_WAVEFRONT}[backend]
     desc = trt.scenes.cornell(384, 384)
     pw, pcam = trt.world_from_description(desc)
     scene = pw.get_bvh()
-    jobs = [(seed, 4 + 2 * (seed % 3)) for seed in range(1, 5)]
+    jobs = [(seed, 4 + 2 * (seed % 3)) for seed in range(1, 7)]
     serial = {}
     for seed, spp in jobs:
         serial[seed] = trt.Renderer(spp, 1, 12, False, desc["background"], seed=seed, backend=be).render(pcam, scene).data.copy()
-    for _ in range(2):
+    for _ in range(3):
         got, errors = {}, []
 
         def work(seed, spp):
@@ -162,6 +162,13 @@ def test_kernel_timing_brackets_the_dominant_kernel(trt):
     r.render(pcam, pw)                                              # disabled again: nothing recorded
     trt._lib.check(trt.lib.trt_kernel_timing_end(C.byref(ms), C.byref(n)))
     assert n.value == 0
+    # several rendering threads at once (one per shard of a multi render): every launch's two events are paired on the thread
+    # that makes the launch, so brackets never mix streams (round 2 paired them by parity in one process-wide list)
+    trt._lib.check(trt.lib.trt_kernel_timing_begin())
+    r.render_multi(pcam, pw, devices=[0, 0, 0])
+    r.render_multi(pcam, pw, devices=[0, 0])
+    trt._lib.check(trt.lib.trt_kernel_timing_end(C.byref(ms), C.byref(n)))
+    assert n.value == 5 and 0.0 < ms.value < 1000.0
 
 
 def test_bench_n2_rehearsal_on_one_gpu():
@@ -189,3 +196,14 @@ def test_bench_n2_rehearsal_on_one_gpu():
     assert d["config"]["samples"] == 3 * 64 * 512 * 500                 # both ranks' samples, every pixel once per sample
     assert d["config"]["image_rows_per_gpu"] == 256                     # 500 rows = 32 bands of 16 (the last one 4 rows): rank 0 owns 16 full bands
     assert "REHEARSAL" in d["config"]["parallelism"] and d["roofline"]["launches_per_step"] >= 1
+
+
+def test_multi_gpu_c_example_renders_identical_frames(tmp_path):
+    """examples/multi_gpu.c: every visible device (two shards on device 0 when there is only one) through trt_render_multi_device
+    into a frame in HBM, ragged last band, then a second accumulating pass: identical to the one-device frame."""
+    import subprocess
+    from test_host_boundary import _build_multi_gpu_example
+    exe = _build_multi_gpu_example(tmp_path)
+    r = subprocess.run([exe, "512", "500", "16"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
+

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(trt):
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} declared in tinyrt.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes table and header disagree"
-    assert trt.lib.trt_abi_version() == 1
+    assert trt.lib.trt_abi_version() == trt._lib.ABI_VERSION == 2
 
 
 def test_pod_layouts_match_reference(trt):
@@ -287,6 +287,26 @@ def test_header_is_valid_c_and_the_c_example_fails_loudly_without_gpu(trt, tmp_p
         assert r.returncode == 1 and "no HIP device visible" in r.stderr
 
 
+def _build_multi_gpu_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "multi_gpu")
+    libdir = os.path.join(ROOT, "tiny-raytracer_amd")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "multi_gpu.c"), "-L" + libdir, "-ltinyrt", "-L/opt/rocm/lib", "-lamdhip64",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], check=True)
+    return exe
+
+
+def test_multi_gpu_example_builds_as_c_and_fails_loudly_without_gpu(trt, tmp_path):
+    """examples/multi_gpu.c: trt_render_multi_device over every visible device into a frame in HBM.  Built here as C11; without a
+    GPU it must say so and exit 2 (on the GPU box tests/test_gpu_multi.py runs it)."""
+    import subprocess
+    exe = _build_multi_gpu_example(tmp_path)
+    if trt.lib.trt_device_count() == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no GPU visible" in r.stderr
+
+
 def test_c_band_layout_equals_the_python_one(trt):
     """trt_render_multi (C, one host thread per device) and tiles.py (one process per GPU over torch.distributed) must cut
     the image the same way: 16-row bands dealt round-robin."""
@@ -303,3 +323,135 @@ def test_c_band_layout_equals_the_python_one(trt):
             assert total == height
     assert trt.lib.trt_band_rows_local(100, 0, 0, C.byref(C.c_uint32())) == -1
     assert trt.lib.trt_band_rows_local(100, 2, 2, C.byref(C.c_uint32())) == -1
+
+
+# ---- round 3: the streamed backend's launch plan and the multi-GPU gather, checked without a device ----
+def _plan(trt, scene, cam, **over):
+    import ctypes as C
+    p = trt.Renderer(64, 1, 50, False, (0.1, 0.1, 0.1)).params(**over)
+    out = trt._lib.LaunchPlan()
+    trt._lib.check(trt.lib.trt_streamed_launch_plan(scene._h, C.byref(cam.pod), C.byref(p), C.byref(out)))
+    return out.as_dict()
+
+
+def _check_plan(pl, stats, tag):
+    """What the kernels assume about their launch (streamed.hip): LDS = scene copy | leaf stack (threads x slots x 8 B) | ray pool
+    (36 B per lane); the lock-step walk pushes two leaves per trip; every plan has an instantiation of the planned shape."""
+    al = (pl["scene_lds_bytes"] + 15) & ~15
+    assert pl["has_kernel"] == 1, tag
+    assert pl["kernel_threads"] == pl["threads_per_workgroup"] and pl["threads_per_workgroup"] in (256, 512, 768), tag
+    assert 1 <= pl["leaf_slots"] <= 16, tag
+    if pl["lds_leaf_stack"]:
+        assert pl["lds_bytes"] == al + pl["threads_per_workgroup"] * pl["leaf_slots"] * 8 + (pl["threads_per_workgroup"] * 36 if pl["ray_pool"] else 0), tag
+    else:
+        assert pl["lds_bytes"] == pl["scene_lds_bytes"] and not pl["ray_pool"] and pl["walk"] == 5, tag
+    assert pl["lds_bytes"] <= 160 * 1024 and pl["lds_bytes"] * pl["workgroups_per_cu"] <= 160 * 1024, tag
+    assert 1 <= pl["workgroups_per_cu"] and pl["workgroups_per_cu"] * pl["threads_per_workgroup"] <= 8 * 256, tag      # <= 8 waves per SIMD
+    assert pl["kernel_ray_pool"] == pl["ray_pool"], tag
+    if pl["walk"] == 2:
+        assert pl["leaf_slots"] >= 2 and pl["lds_leaf_stack"], tag                # walk_flat: limit = stack + 64 * (slots - 2)
+    if pl["walk"] == 3:
+        assert pl["scene_mode"] == 0 and pl["lds_leaf_stack"], tag
+    assert pl["kernel_counting"] == (1 if stats else 0), tag
+    assert pl["kernel_walk"] == (pl["walk"] if pl["specialised"] else 0), tag
+    if pl["kernel_waves_per_simd"] >= 5:
+        # the grid is sized for no more waves per SIMD than the kernel's launch bound provides registers for
+        assert pl["workgroups_per_cu"] * pl["threads_per_workgroup"] <= pl["kernel_waves_per_simd"] * 256 or pl["threads_per_workgroup"] == 768, tag
+    assert pl["workspace_bytes"] > 0 and pl["chunk_spp"] in (1, 2, 4, 8, 16, 32, 64, 128, 256), tag
+
+
+def test_streamed_launch_plan_invariants_for_every_scene_size_and_knob(trt, monkeypatch):
+    """Round 2's GPU suite dumped core ONCE under TRT_STREAM_MINW=8 and nothing kept the reason.  Part of the
+    audit: every (scene size, knob) combination the environment can ask for yields a plan whose LDS parts add up, whose stack is
+    deep enough for its walk, and for which a kernel instantiation of that exact shape exists - checked here for all of them,
+    without a GPU."""
+    import itertools
+    scenes = []
+    scenes.append(("cornell", trt.scenes.cornell(64, 64)))
+    scenes.append(("random_spheres", trt.scenes.random_spheres(64, 48)))
+    for n in (1, 2, 3, 31, 32, 33, 60, 120, 200, 330, 520, 800, 1500):           # LDS-resident sizes on both sides of every threshold
+        scenes.append((f"grid{n}", trt.scenes.sphere_grid(n, 64, 48)))
+    scenes.append(("grid4000", trt.scenes.sphere_grid(4000, 64, 48)))            # read from global memory
+    knobs = {
+        "TRT_STREAM_MINW": (None, "4", "5", "6", "7", "8", "9"),
+        "TRT_LEAF_SLOTS": (None, "1", "2", "3", "4", "8", "16", "64"),
+        "TRT_LDS_LEAF_STACK": (None, "0", "2"),
+        "TRT_RAY_POOL": (None, "0"),
+        "TRT_BIG_THREADS": (None, "512", "768"),
+        "TRT_RUNTIME_WALK": (None, "1"),
+    }
+    n_checked = 0
+    modes = set()
+    for name, desc in scenes:
+        for flat_env in ((None, "0") if name in ("cornell", "grid31") else (None,)):
+            if flat_env is None:
+                monkeypatch.delenv("TRT_FLAT_WALK", raising=False)
+            else:
+                monkeypatch.setenv("TRT_FLAT_WALK", flat_env)
+            w, cam = trt.world_from_description(desc)
+            scene = w.get_bvh()
+            monkeypatch.delenv("TRT_FLAT_WALK", raising=False)
+            for combo in itertools.product(*knobs.values()):
+                for k, v in zip(knobs, combo):
+                    if v is None:
+                        monkeypatch.delenv(k, raising=False)
+                    else:
+                        monkeypatch.setenv(k, v)
+                for stats in (0, 1, 2):
+                    pl = _plan(trt, scene, cam, collect_stats=stats)
+                    _check_plan(pl, stats, (name, flat_env, combo, stats, pl))
+                    modes.add((pl["scene_mode"], pl["walk"], pl["threads_per_workgroup"], pl["ray_pool"]))
+                    n_checked += 1
+    assert n_checked > 20000 and len(modes) >= 8, (n_checked, sorted(modes))
+
+
+def test_default_plans_of_the_three_baseline_scenes(trt, monkeypatch):
+    for k in ("TRT_STREAM_MINW", "TRT_LEAF_SLOTS", "TRT_LDS_LEAF_STACK", "TRT_RAY_POOL", "TRT_BIG_THREADS", "TRT_RUNTIME_WALK", "TRT_FLAT_WALK"):
+        monkeypatch.delenv(k, raising=False)
+    w, cam = trt.world_from_description(trt.scenes.cornell(64, 64))
+    pl = _plan(trt, w.get_bvh(), cam)
+    assert (pl["walk"], pl["threads_per_workgroup"], pl["waves_per_simd"], pl["leaf_slots"], pl["ray_pool"], pl["specialised"]) == (2, 256, 6, 7, 1, 1)
+    w, cam = trt.world_from_description(trt.scenes.random_spheres(64, 48))
+    pl = _plan(trt, w.get_bvh(), cam)
+    assert (pl["walk"], pl["threads_per_workgroup"], pl["workgroups_per_cu"], pl["ray_pool"], pl["specialised"]) == (1, 768, 2, 0, 1)
+    w, cam = trt.world_from_description(trt.scenes.sphere_grid(4000, 64, 48))
+    pl = _plan(trt, w.get_bvh(), cam)
+    assert (pl["scene_mode"], pl["walk"], pl["waves_per_simd"], pl["ray_pool"], pl["specialised"]) == (0, 3, 8, 1, 1)
+
+
+@pytest.mark.parametrize("height", [1, 15, 16, 17, 31, 32, 33, 250, 500, 1080, 2048, 2160])
+@pytest.mark.parametrize("ndev", [1, 2, 3, 8, 13])
+def test_band_copy_plan_places_every_row_exactly_once(trt, height, ndev):
+    """trt_render_multi's gather: one strided 2-D copy per shard (+ one 1-D copy for the ragged last band).  The pitch arithmetic
+    is replayed here on host arrays for ragged heights and more shards than bands, against tiles.band_layout."""
+    import ctypes as C
+    import importlib
+    tiles = importlib.import_module("tiny-raytracer_amd.tiles")
+    width = 5
+    row_bytes = width * 12
+    frame = np.full(height * row_bytes, 0xFF, np.uint8)
+    written = np.zeros(height, np.int32)
+    for rank in range(ndev):
+        pl = trt._lib.BandCopy()
+        trt._lib.check(trt.lib.trt_band_copy_plan(width, height, ndev, rank, C.byref(pl)))
+        lay = tiles.band_layout(height, ndev, rank)
+        rows_local = C.c_uint32()
+        trt._lib.check(trt.lib.trt_band_rows_local(height, ndev, rank, C.byref(rows_local)))
+        assert pl.rows_local == lay["rows_local"] == rows_local.value
+        assert pl.full_bands * 16 + pl.tail_rows == pl.rows_local and pl.tail_rows < 16
+        assert pl.band_bytes == 16 * row_bytes == pl.local_pitch and pl.frame_pitch == ndev * pl.band_bytes
+        local = np.zeros(pl.rows_local * row_bytes, np.uint8)
+        for r, y in enumerate(lay["rows"]):                       # local row r holds image row y: tag every byte with (y mod 251)
+            local[r * row_bytes:(r + 1) * row_bytes] = y % 251
+        for k in range(pl.full_bands):                            # the 2-D copy, row k of it
+            src = k * pl.local_pitch
+            dst = pl.frame_offset + k * pl.frame_pitch
+            assert dst + pl.band_bytes <= frame.size
+            frame[dst:dst + pl.band_bytes] = local[src:src + pl.band_bytes]
+            written[dst // row_bytes:(dst + pl.band_bytes) // row_bytes] += 1
+        if pl.tail_rows:                                          # the 1-D copy
+            assert pl.tail_bytes == pl.tail_rows * row_bytes and pl.tail_frame_offset + pl.tail_bytes == frame.size
+            frame[pl.tail_frame_offset:pl.tail_frame_offset + pl.tail_bytes] = local[pl.tail_local_offset:pl.tail_local_offset + pl.tail_bytes]
+            written[pl.tail_frame_offset // row_bytes:] += 1
+    assert np.all(written == 1)
+    assert np.array_equal(frame.reshape(height, row_bytes)[:, 0], np.arange(height) % 251)

@@ -52,3 +52,34 @@ int main(void) {
                    check=True)
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def _build_capi_host_check(tmp_path, sanitizer):
+    """capi.hip's HOST logic (per-scene pools of workspaces and render contexts, multi-GPU gather, timing brackets, error paths)
+    compiled as plain C++ against the simulated HIP runtime under tests/native/hipstub (streams are worker threads, events complete
+    in stream order, hipFree waits for the device, device memory is the C heap) with stub kernel launchers that stamp and re-check
+    their workspace."""
+    exe = str(tmp_path / ("capi_host_check_" + sanitizer.split(",")[0]))
+    n = os.path.join(ROOT, "tests", "native")
+    c = os.path.join(ROOT, "tiny-raytracer_amd", "csrc")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=" + sanitizer, "-fno-sanitize-recover=all", "-I" + os.path.join(n, "hipstub"),
+                    "-x", "c++", os.path.join(c, "capi.hip"), os.path.join(c, "scene_host.cpp"), os.path.join(n, "launch_stub.cpp"),
+                    os.path.join(n, "hipstub", "hipstub.cpp"), os.path.join(n, "capi_host_check.cpp"), "-lpthread", "-o", exe], check=True)
+    return exe
+
+
+def test_capi_host_logic_under_thread_sanitizer(tmp_path):
+    """Six threads x three repetitions rendering ONE scene (all three backends, mixed sizes), three un-synchronised device streams,
+    1..13 shards over 4 simulated devices into host and device frames (peer access on and off, ragged heights, progressive),
+    timing brackets from five threads at once, the idle-scratch cap, and every HIP call failing once at every position: no data
+    race, no lost update, no leak, every frame right, every error recovered from (part of the audit of
+    round 2's unexplained abort)."""
+    exe = _build_capi_host_check(tmp_path, "thread")
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"), timeout=600)
+    assert r.returncode == 0 and "ok all" in r.stdout and "ThreadSanitizer" not in r.stderr, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+def test_capi_host_logic_under_asan_ubsan(tmp_path):
+    exe = _build_capi_host_check(tmp_path, "address,undefined")
+    r = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"), timeout=600)
+    assert r.returncode == 0 and "ok all" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("TRT_LIB_PATH") or os.path.join(_HERE, "libtinyrt.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 TRT_OK = 0
+ABI_VERSION = 2          # include/tinyrt.h TRT_ABI_VERSION
 ERR_INVALID_ARG, ERR_DUPLICATE, ERR_NOT_FOUND, ERR_HIP, ERR_NO_DEVICE, ERR_OOM = -1, -2, -3, -4, -5, -6
 LAMBERTIAN, METAL, DIELECTRIC, LIGHT = 0, 1, 2, 3
 BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, BACKEND_AUTO, BACKEND_STREAMED = 0, 1, 2, 3
@@ -55,6 +56,22 @@ class CameraPOD(C.Structure):
                 ("width", C.c_uint32), ("height", C.c_uint32)]
 
 
+class BandCopy(C.Structure):
+    _fields_ = [("rows_local", C.c_uint32), ("full_bands", C.c_uint32), ("tail_rows", C.c_uint32), ("reserved", C.c_uint32),
+                ("band_bytes", C.c_uint64), ("local_pitch", C.c_uint64), ("frame_pitch", C.c_uint64), ("frame_offset", C.c_uint64),
+                ("tail_bytes", C.c_uint64), ("tail_local_offset", C.c_uint64), ("tail_frame_offset", C.c_uint64)]
+
+
+class LaunchPlan(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in
+                ("scene_mode", "threads_per_workgroup", "waves_per_simd", "workgroups_per_cu", "lds_bytes", "scene_lds_bytes",
+                 "leaf_slots", "lds_leaf_stack", "ray_pool", "walk", "specialised", "has_kernel", "kernel_waves_per_simd",
+                 "kernel_threads", "kernel_walk", "kernel_ray_pool", "kernel_counting", "chunk_spp")] + [("workspace_bytes", C.c_uint64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
 class RenderParams(C.Structure):
     _fields_ = [("samples_per_pixel", C.c_uint32), ("max_bounces", C.c_uint32), ("background", Vec3),
                 ("seed", C.c_uint32), ("backend", C.c_uint32),
@@ -86,6 +103,7 @@ SIGNATURES = {
     "trt_world_num_materials": (C.c_int, [C.c_void_p]),
     "trt_scene_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "trt_scene_destroy": (None, [C.c_void_p]),
+    "trt_scene_trim": (C.c_int, [C.c_void_p]),
     "trt_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
     "trt_scene_get_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
     "trt_scene_get_cull_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]),
@@ -98,6 +116,8 @@ SIGNATURES = {
     "trt_render_multi_device": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.POINTER(C.c_int),
                                           C.c_uint32, C.c_void_p, C.POINTER(Stats)]),
     "trt_band_rows_local": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "trt_band_copy_plan": (C.c_int, [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(BandCopy)]),
+    "trt_streamed_launch_plan": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.POINTER(LaunchPlan)]),
     "trt_kernel_timing_begin": (C.c_int, []),
     "trt_kernel_timing_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_uint32)]),
     "trt_render_device": (C.c_int, [C.c_void_p, C.POINTER(CameraPOD), C.POINTER(RenderParams), C.c_void_p, C.c_void_p,
@@ -153,7 +173,7 @@ def load():
         fn = getattr(lib, name)            # AttributeError here = ABI symbol missing: fail loudly
         fn.restype = res
         fn.argtypes = args
-    if lib.trt_abi_version() != 1:
+    if lib.trt_abi_version() != ABI_VERSION:
         raise ImportError("libtinyrt.so ABI version mismatch")
     return lib
 

@@ -5,12 +5,26 @@
 // panics on misuse; here every failure is a negative status plus a thread-local message, and no
 // C++ exception leaves this file.  There is no CPU fallback: without a gfx950 device every
 // compute entry point fails with TRT_ERR_NO_DEVICE.
+//
+// Host-side resources (round 3).  Everything a render needs on a device besides the caller's buffers is cached on the scene
+// handle, per device, and lives until trt_scene_destroy / trt_scene_trim:
+//   * the packed scene (uploaded on first use);
+//   * WORKSPACES: the device scratch of one render (streamed: radiance records of a chunk + batch counter; wavefront: path
+//     state).  A render owns its workspace from acquire to release; release records an event behind the render's last kernel
+//     and a workspace is handed out again only to a stream that first waits for that event;
+//   * RENDER CONTEXTS for the blocking entry points (trt_render, trt_render_multi*): a stream, two timing events, the device
+//     counters and a device frame buffer.  Streams are created once and never destroyed while the scene lives, so an event
+//     recorded on one (a workspace's `done`) never outlives its stream.
+// The scene mutex guards only the bookkeeping: an entry is marked busy under the lock and every HIP call that can block
+// (hipMalloc, hipFree, hipEventSynchronize, hipStreamSynchronize) runs with the lock released.
 #include <hip/hip_runtime.h>
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <condition_variable>
 #include <mutex>
 #include <new>
@@ -28,44 +42,87 @@ struct trt_world {
     World w;
 };
 
-// trt_kernel_timing_begin / _end: HIP events around every dominant-kernel launch, process-wide
+// trt_kernel_timing_begin / _end: HIP events around every dominant-kernel launch.  A launcher calls timing_mark(stream, true)
+// before and timing_mark(stream, false) after the launch ON THE SAME HOST THREAD, so the open `begin` is thread-local: pairs
+// never mix threads, streams or devices (round 2 kept one process-wide list and paired marks by parity).
 namespace trt {
 namespace {
 std::mutex g_timing_mu;
 bool g_timing_on = false;
-std::vector<hipEvent_t> g_timing_events;        // begin, end, begin, end, ...
+unsigned g_timing_epoch = 0;                              // bumped by every _begin: a stale thread-local `begin` is dropped
+struct TimingPair { hipEvent_t begin, end; int device; };
+std::vector<TimingPair> g_timing_pairs;                   // completed pairs, appended under g_timing_mu
+struct TimingOpen { hipEvent_t ev = nullptr; hipStream_t stream = nullptr; int device = -1; unsigned epoch = 0; };
+thread_local TimingOpen t_open;
 }  // namespace
 void timing_mark(hipStream_t stream, bool begin) {
-    std::lock_guard<std::mutex> lock(g_timing_mu);
-    if (!g_timing_on) return;
-    if (begin != (g_timing_events.size() % 2 == 0)) return;       // concurrent renders interleaved their marks: keep pairs intact
+    unsigned epoch;
+    {
+        std::lock_guard<std::mutex> lock(g_timing_mu);
+        if (!g_timing_on) return;
+        epoch = g_timing_epoch;
+    }
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (begin) {
+        if (t_open.ev) { (void)hipEventDestroy(t_open.ev); t_open = TimingOpen{}; }       // a begin without its end: dropped
+        hipEvent_t ev = nullptr;
+        if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipEventRecord(ev, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); return; }
+        t_open.ev = ev; t_open.stream = stream; t_open.device = dev; t_open.epoch = epoch;
+        return;
+    }
+    if (!t_open.ev) return;
+    TimingOpen o = t_open;
+    t_open = TimingOpen{};
     hipEvent_t ev = nullptr;
-    if (hipEventCreate(&ev) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (hipEventRecord(ev, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); return; }
-    g_timing_events.push_back(ev);
+    if (o.stream != stream || o.device != dev || o.epoch != epoch || hipEventCreate(&ev) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventDestroy(o.ev);
+        return;
+    }
+    if (hipEventRecord(ev, stream) != hipSuccess) { (void)hipGetLastError(); (void)hipEventDestroy(ev); (void)hipEventDestroy(o.ev); return; }
+    std::lock_guard<std::mutex> lock(g_timing_mu);
+    if (g_timing_on && g_timing_epoch == epoch) g_timing_pairs.push_back(TimingPair{o.ev, ev, dev});
+    else { (void)hipEventDestroy(o.ev); (void)hipEventDestroy(ev); }
 }
 }  // namespace trt
 
-// Device scratch of one render (wavefront: path-state planes; streamed: the radiance records of a chunk + the batch
-// counter).  Renders of one scene may run concurrently - from several host threads, on several streams - so a render
-// never shares a workspace with another one that may still be running: each takes one from a per-(scene, device) pool
-// and gives it back with an event recorded behind its last kernel; a workspace is handed out again only to a stream that
-// first waits for that event (stream-ordered reuse), and the pool prefers workspaces whose event has already fired.
+// Device scratch of one render.  busy: a host thread owns the entry (between acquire and release, or while the pool itself
+// regrows / frees it); recorded: `done` has been recorded behind the last kernel that used the buffer.
 struct Workspace {
     void* ptr = nullptr;
     size_t bytes = 0;
-    hipEvent_t done = nullptr;      // recorded behind the last kernel that used the workspace
+    hipEvent_t done = nullptr;
     bool recorded = false;
-    bool busy = false;              // a host thread is between acquire and release (its launches are not all enqueued yet)
+    bool busy = false;
+};
+// Everything a blocking render call needs on one device besides its workspace.  One call owns a context from acquire to
+// release and has synchronised `stream` before it releases, so an idle context has no work in flight.
+struct RenderCtx {
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* d_ctr = nullptr;          // CTR_COUNT counters
+    float* d_accum = nullptr;                     // device frame (or band) buffer, grown on demand
+    size_t accum_bytes = 0;
+    bool busy = false;
 };
 constexpr size_t kMaxWorkspacesPerDevice = 8;      // beyond that, renders queue behind each other on the device
+constexpr size_t kMaxIdleContextsPerDevice = 16;   // idle contexts beyond that are destroyed at release
+
+struct DeviceCache {
+    float4* blob = nullptr;                       // packed scene in HBM
+    bool blob_busy = false;                       // a thread is uploading it
+    std::vector<Workspace*> ws;
+    std::vector<RenderCtx*> ctx;
+};
 
 struct trt_scene {
     SceneHost host;
     std::mutex mu;
     std::condition_variable cv;
-    std::unordered_map<int, float4*> device_blob;     // device ordinal -> packed scene in HBM
-    std::unordered_map<int, std::vector<Workspace*>> ws_pool;   // device ordinal -> workspaces (grown on demand)
+    std::unordered_map<int, DeviceCache> dev;     // device ordinal -> cached device resources
+    size_t scratch_cap_bytes = (size_t)8 << 30;   // idle scratch (workspaces + context frames) kept per device; TRT_SCRATCH_CAP_MB
 };
 
 namespace {
@@ -95,98 +152,238 @@ int require_device() {
     return TRT_OK;
 }
 
-// Uploads the packed scene to the current device on first use.
+// Uploads the packed scene to the current device on first use.  One thread uploads (lock released during the copy), the
+// others wait for it.
 int scene_on_device(trt_scene* s, SceneDev& out) {
     int dev = 0;
     TRT_HIP(hipGetDevice(&dev));
-    std::lock_guard<std::mutex> lock(s->mu);
-    auto it = s->device_blob.find(dev);
-    float4* d = nullptr;
-    if (it == s->device_blob.end()) {
-        TRT_HIP(hipMalloc(reinterpret_cast<void**>(&d), s->host.layout.blob_bytes));
-        hipError_t e = hipMemcpy(d, s->host.blob.data(), s->host.layout.blob_bytes, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(d); return fail_hip(e, "hipMemcpy(scene)"); }
-        s->device_blob.emplace(dev, d);
-    } else {
-        d = it->second;
+    std::unique_lock<std::mutex> lock(s->mu);
+    DeviceCache& dc = s->dev[dev];                              // references into an unordered_map stay valid across inserts
+    while (dc.blob == nullptr && dc.blob_busy) s->cv.wait(lock);
+    if (dc.blob == nullptr) {
+        dc.blob_busy = true;
+        lock.unlock();
+        float4* d = nullptr;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d), s->host.layout.blob_bytes);
+        if (e == hipSuccess) {
+            e = hipMemcpy(d, s->host.blob.data(), s->host.layout.blob_bytes, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(d); d = nullptr; }
+        }
+        lock.lock();
+        dc.blob_busy = false;
+        dc.blob = d;
+        s->cv.notify_all();
+        if (e != hipSuccess) return fail_hip(e, "scene upload");
     }
-    out.blob = d;
+    out.blob = dc.blob;
     out.L = s->host.layout;
     return TRT_OK;
+}
+
+bool ws_finished(Workspace* w) {                                  // call with the scene lock held, entry not busy
+    if (!w->recorded) return true;
+    const bool done = hipEventQuery(w->done) == hipSuccess;
+    (void)hipGetLastError();                                      // hipErrorNotReady is not an error
+    return done;
+}
+
+// Frees idle scratch on `dc` until at most `cap` bytes of IDLE scratch stay cached (largest first).  Called with the lock held; the
+// hipFree calls run with the lock released (the entries are marked busy meanwhile).
+void trim_locked(trt_scene* s, std::unique_lock<std::mutex>& lock, DeviceCache& dc, size_t cap) {
+    for (;;) {
+        size_t total = 0;                                         // idle entries only: a busy entry's fields belong to its owner
+        for (Workspace* w : dc.ws) if (!w->busy) total += w->bytes;
+        for (RenderCtx* c : dc.ctx) if (!c->busy) total += c->accum_bytes;
+        if (total <= cap) return;
+        Workspace* bw = nullptr;
+        RenderCtx* bc = nullptr;
+        for (Workspace* w : dc.ws) if (!w->busy && w->bytes && ws_finished(w) && (!bw || w->bytes > bw->bytes)) bw = w;
+        for (RenderCtx* c : dc.ctx) if (!c->busy && c->accum_bytes && (!bc || c->accum_bytes > bc->accum_bytes)) bc = c;
+        if (!bw && !bc) return;                                   // everything left is in use
+        void* victim;
+        if (bw && (!bc || bw->bytes >= bc->accum_bytes)) { bw->busy = true; victim = bw->ptr; bw->ptr = nullptr; bw->bytes = 0; bw->recorded = false; bc = nullptr; }
+        else { bc->busy = true; victim = bc->d_accum; bc->d_accum = nullptr; bc->accum_bytes = 0; bw = nullptr; }
+        lock.unlock();
+        (void)hipFree(victim);
+        (void)hipGetLastError();
+        lock.lock();
+        if (bw) bw->busy = false; else bc->busy = false;
+        s->cv.notify_all();
+    }
 }
 
 // Takes a workspace of at least `need` bytes for a render that will be enqueued on `stream` of device `dev`.
 int workspace_acquire(trt_scene* s, int dev, size_t need, hipStream_t stream, Workspace** out) {
     std::unique_lock<std::mutex> lock(s->mu);
-    std::vector<Workspace*>& pool = s->ws_pool[dev];
+    DeviceCache& dc = s->dev[dev];
+    bool may_grow = true;
     for (;;) {
+        // 1. an idle one whose last render has finished (no dependency at all): the smallest that fits, else one to regrow
         Workspace* pick = nullptr;
-        // 1. an idle one whose last render has finished (no dependency at all); the smallest that fits, else any to regrow
-        Workspace* finished_small = nullptr;
-        for (Workspace* w : pool) {
-            if (w->busy) continue;
-            const bool finished = !w->recorded || hipEventQuery(w->done) == hipSuccess;
-            if (!finished) continue;
+        Workspace* regrow = nullptr;
+        for (Workspace* w : dc.ws) {
+            if (w->busy || !ws_finished(w)) continue;
             if (w->bytes >= need) { if (!pick || w->bytes < pick->bytes) pick = w; }
-            else if (!finished_small) finished_small = w;
+            else if (!regrow) regrow = w;
         }
-        (void)hipGetLastError();                              // hipEventQuery's hipErrorNotReady is not an error
-        if (!pick && finished_small) {                        // grow a finished one in place
-            Workspace* w = finished_small;
-            if (w->ptr) { hipError_t e = hipFree(w->ptr); w->ptr = nullptr; w->bytes = 0; if (e != hipSuccess) return fail_hip(e, "hipFree(workspace)"); }
-            hipError_t e = hipMalloc(&w->ptr, need);
-            if (e != hipSuccess) { w->ptr = nullptr; return fail_hip(e, "hipMalloc(workspace)"); }
-            w->bytes = need;
-            w->recorded = false;
-            pick = w;
-        }
+        enum { USE, REGROW, CREATE, QUEUE, DRAIN } what = USE;
+        if (!pick && regrow) { pick = regrow; what = REGROW; }
         // 2. a new one while the pool may grow
-        if (!pick && pool.size() < kMaxWorkspacesPerDevice) {
-            Workspace* w = new (std::nothrow) Workspace();
-            if (!w) return fail(TRT_ERR_OOM, "out of memory");
-            hipError_t e = hipEventCreateWithFlags(&w->done, hipEventDisableTiming);
-            if (e == hipSuccess) e = hipMalloc(&w->ptr, need);
-            if (e != hipSuccess) {
-                if (w->done) (void)hipEventDestroy(w->done);
-                delete w;
-                if (pool.empty()) return fail_hip(e, "hipMalloc(workspace)");
-                (void)hipGetLastError();                      // out of HBM for another copy: queue behind a running render instead
-            } else {
-                w->bytes = need;
-                pool.push_back(w);
-                pick = w;
-            }
+        if (!pick && may_grow && dc.ws.size() < kMaxWorkspacesPerDevice) {
+            pick = new (std::nothrow) Workspace();
+            if (!pick) return fail(TRT_ERR_OOM, "out of memory");
+            dc.ws.push_back(pick);
+            what = CREATE;
         }
         // 3. an idle one that is still in flight and large enough: this render queues behind it on the device
         if (!pick) {
-            for (Workspace* w : pool) if (!w->busy && w->bytes >= need) { pick = w; break; }
+            for (Workspace* w : dc.ws) if (!w->busy && w->bytes >= need) { pick = w; what = QUEUE; break; }
         }
-        if (pick) {
-            if (pick->recorded) TRT_HIP(hipStreamWaitEvent(stream, pick->done, 0));
-            pick->busy = true;
-            *out = pick;
-            return TRT_OK;
+        if (!pick) {
+            // 4. every workspace is owned by another host thread: wait for a release
+            bool any_busy = false;
+            for (Workspace* w : dc.ws) any_busy = any_busy || w->busy;
+            if (any_busy) { s->cv.wait(lock); continue; }
+            if (dc.ws.empty()) return fail(TRT_ERR_OOM, "no device memory for a render workspace");
+            // 5. all idle, all in flight, all too small: wait for the first to finish, then regrow it
+            pick = dc.ws.front();
+            what = DRAIN;
         }
-        // 4. every workspace is being enqueued on by another host thread, or is in flight and too small: wait for a release
-        bool any_busy = false;
-        for (Workspace* w : pool) any_busy = any_busy || w->busy;
-        if (any_busy) { s->cv.wait(lock); continue; }
-        // all idle, all in flight, all too small: wait for the first to finish, then regrow it
-        TRT_HIP(hipEventSynchronize(pool.front()->done));
+        pick->busy = true;
+        lock.unlock();
+        // ---- HIP calls, lock released; `pick` is ours ----
+        hipError_t e = hipSuccess;
+        const char* where = "";
+        if (what == CREATE) {
+            e = hipEventCreateWithFlags(&pick->done, hipEventDisableTiming); where = "hipEventCreate(workspace)";
+            if (e == hipSuccess) { e = hipMalloc(&pick->ptr, need); where = "hipMalloc(workspace)"; if (e == hipSuccess) pick->bytes = need; else pick->ptr = nullptr; }
+        } else if (what == DRAIN || what == REGROW) {
+            if (what == DRAIN) { e = hipEventSynchronize(pick->done); where = "hipEventSynchronize(workspace)"; }
+            if (e == hipSuccess && pick->ptr) { e = hipFree(pick->ptr); where = "hipFree(workspace)"; pick->ptr = nullptr; pick->bytes = 0; }
+            if (e == hipSuccess) { e = hipMalloc(&pick->ptr, need); where = "hipMalloc(workspace)"; if (e == hipSuccess) pick->bytes = need; else pick->ptr = nullptr; }
+            if (e == hipSuccess) pick->recorded = false;
+        } else if (what == QUEUE) {
+            e = hipStreamWaitEvent(stream, pick->done, 0); where = "hipStreamWaitEvent(workspace)";
+        }
+        if (e == hipSuccess) { *out = pick; return TRT_OK; }
+        (void)hipGetLastError();
+        lock.lock();
+        if (what == CREATE) {
+            dc.ws.erase(std::find(dc.ws.begin(), dc.ws.end(), pick));
+            if (pick->done) (void)hipEventDestroy(pick->done);
+            delete pick;
+            s->cv.notify_all();
+            if (e == hipErrorOutOfMemory && !dc.ws.empty()) { may_grow = false; continue; }     // out of HBM for another copy: queue behind a running render instead
+            return fail_hip(e, where);
+        }
+        pick->busy = false;                                       // (a failed regrow leaves an empty, reusable entry)
+        s->cv.notify_all();
+        return fail_hip(e, where);
     }
 }
 
 // Gives the workspace back; `stream` has all of the render's launches enqueued.
-int workspace_release(trt_scene* s, Workspace* w, hipStream_t stream) {
-    const hipError_t e = hipEventRecord(w->done, stream);
+int workspace_release(trt_scene* s, int dev, Workspace* w, hipStream_t stream) {
+    hipError_t e = hipEventRecord(w->done, stream);
+    bool recorded = e == hipSuccess;
+    if (!recorded) {
+        // without the event nothing orders the next user behind this render: wait for the render itself
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream);
+        (void)hipGetLastError();
+    }
     {
-        std::lock_guard<std::mutex> lock(s->mu);
-        w->recorded = (e == hipSuccess);
+        std::unique_lock<std::mutex> lock(s->mu);
+        w->recorded = recorded;
         w->busy = false;
+        trim_locked(s, lock, s->dev[dev], s->scratch_cap_bytes);
     }
     s->cv.notify_all();
     if (e != hipSuccess) return fail_hip(e, "hipEventRecord(workspace)");
     return TRT_OK;
+}
+
+// A render context on the current device with a device frame of at least `accum_bytes` (0: none needed).
+int context_acquire(trt_scene* s, int dev, size_t accum_bytes, RenderCtx** out) {
+    RenderCtx* c = nullptr;
+    bool fresh = false;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        DeviceCache& dc = s->dev[dev];
+        RenderCtx* fits = nullptr;                                 // the smallest idle frame that fits, else the largest idle one (regrown)
+        RenderCtx* any = nullptr;
+        for (RenderCtx* k : dc.ctx) {
+            if (k->busy) continue;
+            if (k->accum_bytes >= accum_bytes && (!fits || k->accum_bytes < fits->accum_bytes)) fits = k;
+            if (!any || k->accum_bytes > any->accum_bytes) any = k;
+        }
+        c = fits ? fits : any;
+        if (!c) {
+            c = new (std::nothrow) RenderCtx();
+            if (!c) return fail(TRT_ERR_OOM, "out of memory");
+            dc.ctx.push_back(c);
+            fresh = true;
+        }
+        c->busy = true;
+    }
+    hipError_t e = hipSuccess;
+    const char* where = "";
+    if (fresh) {
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking); where = "hipStreamCreate";
+        if (e == hipSuccess) { e = hipEventCreate(&c->ev0); where = "hipEventCreate"; }
+        if (e == hipSuccess) { e = hipEventCreate(&c->ev1); where = "hipEventCreate"; }
+        if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&c->d_ctr), CTR_COUNT * sizeof(unsigned long long)); where = "hipMalloc(counters)"; }
+    }
+    if (e == hipSuccess && c->accum_bytes < accum_bytes) {
+        if (c->d_accum) { e = hipFree(c->d_accum); where = "hipFree(frame)"; c->d_accum = nullptr; c->accum_bytes = 0; }
+        if (e == hipSuccess) { e = hipMalloc(reinterpret_cast<void**>(&c->d_accum), accum_bytes); where = "hipMalloc(frame)"; if (e == hipSuccess) c->accum_bytes = accum_bytes; else c->d_accum = nullptr; }
+    }
+    if (e == hipSuccess) { *out = c; return TRT_OK; }
+    (void)hipGetLastError();
+    const int rc = fail_hip(e, where);
+    std::lock_guard<std::mutex> lock(s->mu);
+    if (fresh) {                                                  // half-built: take it out of the pool again
+        DeviceCache& dc = s->dev[dev];
+        dc.ctx.erase(std::find(dc.ctx.begin(), dc.ctx.end(), c));
+        if (c->d_ctr) (void)hipFree(c->d_ctr);
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+    } else {
+        c->busy = false;
+    }
+    return rc;
+}
+
+void context_destroy(RenderCtx* c) {                              // idle context: nothing in flight on its stream
+    if (c->d_accum) (void)hipFree(c->d_accum);
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    (void)hipGetLastError();
+    delete c;
+}
+
+// The caller has synchronised c->stream (or nothing was enqueued on it).
+void context_release(trt_scene* s, int dev, RenderCtx* c) {
+    std::vector<RenderCtx*> surplus;
+    {
+        std::unique_lock<std::mutex> lock(s->mu);
+        DeviceCache& dc = s->dev[dev];
+        c->busy = false;
+        size_t idle = 0;
+        for (RenderCtx* k : dc.ctx) idle += k->busy ? 0u : 1u;
+        while (idle > kMaxIdleContextsPerDevice) {                // a burst of shards: keep the pool bounded
+            auto it = std::find_if(dc.ctx.begin(), dc.ctx.end(), [](RenderCtx* k) { return !k->busy; });
+            surplus.push_back(*it);
+            dc.ctx.erase(it);
+            idle--;
+        }
+        trim_locked(s, lock, dc, s->scratch_cap_bytes);
+    }
+    for (RenderCtx* k : surplus) context_destroy(k);
 }
 
 void to_camera_dev(const trt_camera& c, CameraDev& d) {
@@ -274,7 +471,7 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
             le = launch_wavefront(sc, cd, ra, ws->ptr, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0,
                                   serve_min, stream);
         }
-        rc = workspace_release(s, ws, stream);
+        rc = workspace_release(s, dev, ws, stream);
         if (le != hipSuccess) return fail_hip(le, streamed ? "launch_streamed" : "launch_wavefront");
         return rc;
     }
@@ -369,27 +566,50 @@ int trt_scene_create(const trt_world* w, trt_scene** out) {
         trt_scene* s = new trt_scene();
         std::string msg;
         if (!compile_scene(w->w, s->host, msg)) { delete s; return fail(TRT_ERR_INVALID_ARG, msg); }
+        if (const char* e = getenv("TRT_SCRATCH_CAP_MB")) s->scratch_cap_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
         *out = s;
     } catch (const std::bad_alloc&) {
         return fail(TRT_ERR_OOM, "out of memory");
     }
     return TRT_OK;
 }
+// Frees every idle cached device buffer of the scene (workspaces whose render has finished, idle contexts' frames); the
+// packed scene stays.  Safe while renders of the scene run: what they own is skipped.
+int trt_scene_trim(trt_scene* s) {
+    if (!s) return fail(TRT_ERR_INVALID_ARG, "scene is null");
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    std::vector<int> devices;
+    {
+        std::lock_guard<std::mutex> lock(s->mu);
+        for (auto& kv : s->dev) devices.push_back(kv.first);
+    }
+    for (int d : devices) {
+        if (hipSetDevice(d) != hipSuccess) continue;
+        std::unique_lock<std::mutex> lock(s->mu);
+        trim_locked(s, lock, s->dev[d], 0);
+    }
+    if (have_prev) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
+    return TRT_OK;
+}
+// Must not run while another host thread is inside a render call on this scene.  Renders enqueued through trt_render_device
+// that are still running on the device are waited for (their workspace events) before anything is freed.
 void trt_scene_destroy(trt_scene* s) {
     if (!s) return;
     int prev = 0;
     const bool have_prev = hipGetDevice(&prev) == hipSuccess;
-    for (auto& kv : s->ws_pool) {
+    for (auto& kv : s->dev) {
         if (hipSetDevice(kv.first) != hipSuccess) continue;
-        for (Workspace* w : kv.second) {
+        DeviceCache& dc = kv.second;
+        for (Workspace* w : dc.ws) {
             if (w->recorded) (void)hipEventSynchronize(w->done);      // a render may still be using it
             if (w->ptr) (void)hipFree(w->ptr);
             if (w->done) (void)hipEventDestroy(w->done);
             delete w;
         }
-    }
-    for (auto& kv : s->device_blob) {
-        if (hipSetDevice(kv.first) == hipSuccess) (void)hipFree(kv.second);
+        for (RenderCtx* c : dc.ctx) context_destroy(c);               // after the workspaces: their events were recorded on these streams
+        if (dc.blob) (void)hipFree(dc.blob);
     }
     if (have_prev) (void)hipSetDevice(prev);
     (void)hipGetLastError();
@@ -457,40 +677,37 @@ int trt_render(trt_scene* s, const trt_camera* cam, const trt_render_params* p, 
     rc = to_render_args(cam, p, probe, rows);
     if (rc != TRT_OK) return rc;
     const size_t bytes = (size_t)rows * cam->width * 3 * sizeof(float);
-    float* d_accum = nullptr;
-    unsigned long long* d_ctr = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int dev = 0;
+    TRT_HIP(hipGetDevice(&dev));
+    RenderCtx* c = nullptr;
+    rc = context_acquire(s, dev, bytes ? bytes : 16, &c);
+    if (rc != TRT_OK) return rc;
     unsigned long long h_ctr[CTR_COUNT] = {0};
     float ms = 0.0f;
-    auto cleanup = [&]() {
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
-        if (d_accum) (void)hipFree(d_accum);
-        if (d_ctr) (void)hipFree(d_ctr);
+    // from here on every exit drains the context's stream before the context goes back to the pool
+    auto finish = [&](int code) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        context_release(s, dev, c);
+        return code;
     };
 #define TRT_HIP_C(call)                                                          \
     do {                                                                         \
         hipError_t e_ = (call);                                                  \
-        if (e_ != hipSuccess) { cleanup(); return fail_hip(e_, #call); }         \
+        if (e_ != hipSuccess) return finish(fail_hip(e_, #call));                \
     } while (0)
-    TRT_HIP_C(hipStreamCreate(&stream));
-    TRT_HIP_C(hipEventCreate(&ev0));
-    TRT_HIP_C(hipEventCreate(&ev1));
-    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_accum), bytes ? bytes : 16));
-    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_ctr), sizeof(h_ctr)));
-    TRT_HIP_C(hipMemsetAsync(d_ctr, 0, sizeof(h_ctr), stream));
-    if (p->accumulate && bytes) TRT_HIP_C(hipMemcpyAsync(d_accum, accum, bytes, hipMemcpyHostToDevice, stream));
-    TRT_HIP_C(hipEventRecord(ev0, stream));
-    rc = enqueue_render(s, cam, p, d_accum, reinterpret_cast<uint64_t*>(d_ctr), stream, nullptr);
-    if (rc != TRT_OK) { cleanup(); return rc; }
-    TRT_HIP_C(hipEventRecord(ev1, stream));
-    if (bytes) TRT_HIP_C(hipMemcpyAsync(accum, d_accum, bytes, hipMemcpyDeviceToHost, stream));
-    TRT_HIP_C(hipMemcpyAsync(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, stream));
-    TRT_HIP_C(hipStreamSynchronize(stream));
-    TRT_HIP_C(hipEventElapsedTime(&ms, ev0, ev1));
-    cleanup();
+    TRT_HIP_C(hipMemsetAsync(c->d_ctr, 0, sizeof(h_ctr), c->stream));
+    if (p->accumulate && bytes) TRT_HIP_C(hipMemcpyAsync(c->d_accum, accum, bytes, hipMemcpyHostToDevice, c->stream));
+    TRT_HIP_C(hipEventRecord(c->ev0, c->stream));
+    rc = enqueue_render(s, cam, p, c->d_accum, reinterpret_cast<uint64_t*>(c->d_ctr), c->stream, nullptr);
+    if (rc != TRT_OK) return finish(rc);
+    TRT_HIP_C(hipEventRecord(c->ev1, c->stream));
+    if (bytes) TRT_HIP_C(hipMemcpyAsync(accum, c->d_accum, bytes, hipMemcpyDeviceToHost, c->stream));
+    TRT_HIP_C(hipMemcpyAsync(h_ctr, c->d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, c->stream));
+    TRT_HIP_C(hipStreamSynchronize(c->stream));
+    TRT_HIP_C(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+#undef TRT_HIP_C
+    context_release(s, dev, c);
     if (stats) { counters_to_stats(h_ctr, stats); stats->kernel_ms = ms; }
     return TRT_OK;
 }
@@ -499,11 +716,13 @@ int trt_render(trt_scene* s, const trt_camera* cam, const trt_render_params* p, 
 //
 // renderer.rs:37-79 is ONE call that returns the whole Image; so is this.  The path shards by pixels (every sample reads
 // only the immutable scene, cpu.rs:39-65): the scene is replicated, the image is cut into bands of kMultiBandRows rows dealt
-// round-robin (band b -> device b % ndev, so expensive regions spread over all devices), the RNG is keyed by the image
+// round-robin (band b -> shard b % ndev, so expensive regions spread over all devices), the RNG is keyed by the image
 // pixel, and every device folds its own pixels in sample order - the frame is bit-identical for every ndev.  One host
-// thread per device enqueues that device's bands on a stream of its own; the only exchange is the gather of the
-// finished f32 sums: each band goes straight to its place in the destination frame (a host buffer: one D2H copy per
-// band; a buffer on devices[0]: one peer copy over xGMI per band), so no un-interleave pass exists.
+// thread per shard drives its device on a cached context (stream, events, counters, band buffer: nothing is created per
+// call once the pool is warm).  The only exchange is the gather of the finished f32 sums: a shard's bands sit at a
+// constant pitch of ndev x 16 rows in the frame, so ONE strided 2-D copy moves all its full bands straight to their place
+// (a host buffer: D2H; a buffer on devices[0]: device to device over xGMI), plus one 1-D copy if the shard owns the ragged
+// last band.  No padded gather buffer and no un-interleave pass exist.
 namespace {
 
 constexpr uint32_t kMultiBandRows = 16;
@@ -511,6 +730,7 @@ constexpr uint32_t kMultiBandRows = 16;
 struct MultiShard {
     int device = 0;
     uint32_t rank = 0, rows_local = 0;
+    bool peer_ok = true;                      // the gather may address the destination device directly
     int rc = TRT_OK;
     std::string error;
     unsigned long long ctr[CTR_COUNT] = {0};
@@ -524,71 +744,92 @@ uint32_t band_rows_local(uint32_t height, uint32_t ndev, uint32_t rank, uint32_t
     return rows;
 }
 
+// Where shard `rank` of `ndev` keeps its rows and where they belong in the frame (bytes).  Local rows are contiguous; in the
+// frame the shard's k-th band starts at row (k * ndev + rank) * 16.
+void band_copy_plan(uint32_t width, uint32_t height, uint32_t ndev, uint32_t rank, trt_band_copy* o) {
+    const uint64_t row_bytes = (uint64_t)width * 3u * sizeof(float);
+    const uint32_t rows = band_rows_local(height, ndev, rank, kMultiBandRows);
+    o->rows_local = rows;
+    o->full_bands = rows / kMultiBandRows;
+    o->tail_rows = rows % kMultiBandRows;                                   // only the image's last band can be short
+    o->band_bytes = row_bytes * kMultiBandRows;
+    o->local_pitch = o->band_bytes;
+    o->frame_pitch = o->band_bytes * ndev;
+    o->frame_offset = (uint64_t)rank * o->band_bytes;
+    o->tail_bytes = row_bytes * o->tail_rows;
+    o->tail_local_offset = (uint64_t)o->full_bands * o->band_bytes;
+    o->tail_frame_offset = ((uint64_t)o->full_bands * ndev + rank) * o->band_bytes;
+}
+
+// Moves one shard's rows between its local buffer and the frame (to_frame: the gather; else: reading the running sums).
+hipError_t copy_bands(const trt_band_copy& pl, char* local, char* frame, bool to_frame, int local_device, int frame_device,
+                      bool peer_ok, hipStream_t stream) {
+    const bool host_frame = frame_device < 0;
+    const hipMemcpyKind kind = host_frame ? (to_frame ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice) : hipMemcpyDeviceToDevice;
+    const bool direct = host_frame || frame_device == local_device || peer_ok;
+    if (pl.full_bands) {
+        if (direct) {
+            hipError_t e = to_frame
+                ? hipMemcpy2DAsync(frame + pl.frame_offset, pl.frame_pitch, local, pl.local_pitch, pl.band_bytes, pl.full_bands, kind, stream)
+                : hipMemcpy2DAsync(local, pl.local_pitch, frame + pl.frame_offset, pl.frame_pitch, pl.band_bytes, pl.full_bands, kind, stream);
+            if (e != hipSuccess) return e;
+        } else {                                                  // no peer access: the runtime stages each band through the host
+            for (uint32_t k = 0; k < pl.full_bands; k++) {
+                char* l = local + (uint64_t)k * pl.local_pitch;
+                char* f = frame + pl.frame_offset + (uint64_t)k * pl.frame_pitch;
+                hipError_t e = to_frame ? hipMemcpyPeerAsync(f, frame_device, l, local_device, pl.band_bytes, stream)
+                                        : hipMemcpyPeerAsync(l, local_device, f, frame_device, pl.band_bytes, stream);
+                if (e != hipSuccess) return e;
+            }
+        }
+    }
+    if (pl.tail_rows) {
+        char* l = local + pl.tail_local_offset;
+        char* f = frame + pl.tail_frame_offset;
+        if (direct) return to_frame ? hipMemcpyAsync(f, l, pl.tail_bytes, kind, stream) : hipMemcpyAsync(l, f, pl.tail_bytes, kind, stream);
+        return to_frame ? hipMemcpyPeerAsync(f, frame_device, l, local_device, pl.tail_bytes, stream)
+                        : hipMemcpyPeerAsync(l, local_device, f, frame_device, pl.tail_bytes, stream);
+    }
+    return hipSuccess;
+}
+
 // One device's share.  dst: the whole frame, on the host (dst_device < 0) or on device dst_device.
 void render_shard(trt_scene* s, const trt_camera* cam, const trt_render_params* p, uint32_t ndev, MultiShard* sh, float* dst,
                   int dst_device) {
-    float* d_accum = nullptr;
-    unsigned long long* d_ctr = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    auto cleanup = [&]() {
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamDestroy(stream);
-        if (d_accum) (void)hipFree(d_accum);
-        if (d_ctr) (void)hipFree(d_ctr);
+    hipError_t e = hipSetDevice(sh->device);
+    if (e != hipSuccess) { sh->rc = fail_hip(e, "hipSetDevice"); sh->error = g_last_error; return; }
+    if (sh->rows_local == 0) return;                                        // more shards than bands
+    trt_band_copy pl;
+    band_copy_plan(cam->width, cam->height, ndev, sh->rank, &pl);
+    trt_render_params q = *p;
+    q.band_rows = kMultiBandRows; q.band_stride = ndev; q.band_offset = sh->rank; q.rows_local = sh->rows_local;
+    RenderCtx* c = nullptr;
+    sh->rc = context_acquire(s, sh->device, (size_t)pl.rows_local * cam->width * 3 * sizeof(float), &c);
+    if (sh->rc != TRT_OK) { sh->error = g_last_error; return; }
+    auto finish = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        context_release(s, sh->device, c);
     };
 #define TRT_HIP_S(call)                                                                                         \
     do {                                                                                                        \
         hipError_t e_ = (call);                                                                                 \
-        if (e_ != hipSuccess) { sh->rc = fail_hip(e_, #call); sh->error = g_last_error; cleanup(); return; }    \
+        if (e_ != hipSuccess) { sh->rc = fail_hip(e_, #call); sh->error = g_last_error; finish(); return; }     \
     } while (0)
-    TRT_HIP_S(hipSetDevice(sh->device));
-    if (sh->rows_local == 0) return;                                        // more devices than bands
-    const size_t row_bytes = (size_t)cam->width * 3 * sizeof(float);
-    trt_render_params q = *p;
-    q.band_rows = kMultiBandRows; q.band_stride = ndev; q.band_offset = sh->rank; q.rows_local = sh->rows_local;
-    TRT_HIP_S(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    TRT_HIP_S(hipEventCreate(&ev0));
-    TRT_HIP_S(hipEventCreate(&ev1));
-    TRT_HIP_S(hipMalloc(reinterpret_cast<void**>(&d_accum), row_bytes * sh->rows_local));
-    TRT_HIP_S(hipMalloc(reinterpret_cast<void**>(&d_ctr), sizeof(sh->ctr)));
-    TRT_HIP_S(hipMemsetAsync(d_ctr, 0, sizeof(sh->ctr), stream));
-    // local rows [r0, r0 + n) = image rows [y0, y0 + n): one contiguous band
-    auto for_each_band = [&](auto&& fn) -> hipError_t {
-        uint32_t r0 = 0;
-        for (uint32_t b = sh->rank; r0 < sh->rows_local; b += ndev) {
-            const uint32_t y0 = b * kMultiBandRows;
-            const uint32_t n = y0 + kMultiBandRows <= cam->height ? kMultiBandRows : cam->height - y0;
-            hipError_t e = fn(r0, y0, n);
-            if (e != hipSuccess) return e;
-            r0 += n;
-        }
-        return hipSuccess;
-    };
-    if (p->accumulate) {                                                    // continue the running sums of the frame
-        TRT_HIP_S(for_each_band([&](uint32_t r0, uint32_t y0, uint32_t n) {
-            float* local = d_accum + (size_t)r0 * cam->width * 3;
-            const float* frame = dst + (size_t)y0 * cam->width * 3;
-            return dst_device < 0 ? hipMemcpyAsync(local, frame, row_bytes * n, hipMemcpyHostToDevice, stream)
-                                  : hipMemcpyPeerAsync(local, sh->device, frame, dst_device, row_bytes * n, stream);
-        }));
-    }
-    TRT_HIP_S(hipEventRecord(ev0, stream));
-    sh->rc = enqueue_render(s, cam, &q, d_accum, reinterpret_cast<uint64_t*>(d_ctr), stream, nullptr);
-    if (sh->rc != TRT_OK) { sh->error = g_last_error; (void)hipStreamSynchronize(stream); cleanup(); return; }
-    TRT_HIP_S(hipEventRecord(ev1, stream));
-    TRT_HIP_S(for_each_band([&](uint32_t r0, uint32_t y0, uint32_t n) {     // the gather: every band to its place in the frame
-        const float* local = d_accum + (size_t)r0 * cam->width * 3;
-        float* frame = dst + (size_t)y0 * cam->width * 3;
-        return dst_device < 0 ? hipMemcpyAsync(frame, local, row_bytes * n, hipMemcpyDeviceToHost, stream)
-                              : hipMemcpyPeerAsync(frame, dst_device, local, sh->device, row_bytes * n, stream);
-    }));
-    TRT_HIP_S(hipMemcpyAsync(sh->ctr, d_ctr, sizeof(sh->ctr), hipMemcpyDeviceToHost, stream));
-    TRT_HIP_S(hipStreamSynchronize(stream));
-    TRT_HIP_S(hipEventElapsedTime(&sh->ms, ev0, ev1));
-    cleanup();
+    char* local = reinterpret_cast<char*>(c->d_accum);
+    char* frame = reinterpret_cast<char*>(dst);
+    TRT_HIP_S(hipMemsetAsync(c->d_ctr, 0, sizeof(sh->ctr), c->stream));
+    if (p->accumulate) TRT_HIP_S(copy_bands(pl, local, frame, false, sh->device, dst_device, sh->peer_ok, c->stream));   // continue the frame's running sums
+    TRT_HIP_S(hipEventRecord(c->ev0, c->stream));
+    sh->rc = enqueue_render(s, cam, &q, c->d_accum, reinterpret_cast<uint64_t*>(c->d_ctr), c->stream, nullptr);
+    if (sh->rc != TRT_OK) { sh->error = g_last_error; finish(); return; }
+    TRT_HIP_S(hipEventRecord(c->ev1, c->stream));
+    TRT_HIP_S(copy_bands(pl, local, frame, true, sh->device, dst_device, sh->peer_ok, c->stream));                       // the gather
+    TRT_HIP_S(hipMemcpyAsync(sh->ctr, c->d_ctr, sizeof(sh->ctr), hipMemcpyDeviceToHost, c->stream));
+    TRT_HIP_S(hipStreamSynchronize(c->stream));
+    TRT_HIP_S(hipEventElapsedTime(&sh->ms, c->ev0, c->ev1));
 #undef TRT_HIP_S
+    context_release(s, sh->device, c);
 }
 
 int render_multi(trt_scene* s, const trt_camera* cam, const trt_render_params* p, const int* devices, uint32_t ndev, float* dst,
@@ -618,13 +859,14 @@ int render_multi(trt_scene* s, const trt_camera* cam, const trt_render_params* p
     TRT_HIP(hipGetDevice(&prev));
     const int dst_device = dst_on_device ? shards[0].device : -1;
     if (dst_on_device) {
-        for (uint32_t r = 1; r < ndev; r++) {                               // peer access for the gather (xGMI)
+        for (uint32_t r = 0; r < ndev; r++) {                               // peer access for the gather (xGMI)
             if (shards[r].device == dst_device) continue;
             int can = 0;
-            TRT_HIP(hipDeviceCanAccessPeer(&can, shards[r].device, dst_device));
-            if (!can) continue;                                             // hipMemcpyPeerAsync then stages through the host
-            TRT_HIP(hipSetDevice(shards[r].device));
-            hipError_t e = hipDeviceEnablePeerAccess(dst_device, 0);
+            hipError_t e = hipDeviceCanAccessPeer(&can, shards[r].device, dst_device);
+            if (e != hipSuccess) { (void)hipSetDevice(prev); return fail_hip(e, "hipDeviceCanAccessPeer"); }
+            if (!can) { shards[r].peer_ok = false; continue; }             // hipMemcpyPeerAsync then stages through the host
+            e = hipSetDevice(shards[r].device);
+            if (e == hipSuccess) e = hipDeviceEnablePeerAccess(dst_device, 0);
             if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipSetDevice(prev); return fail_hip(e, "hipDeviceEnablePeerAccess"); }
             (void)hipGetLastError();
         }
@@ -681,6 +923,12 @@ int trt_band_rows_local(uint32_t height, uint32_t ndev, uint32_t rank, uint32_t*
     return TRT_OK;
 }
 
+int trt_band_copy_plan(uint32_t width, uint32_t height, uint32_t ndev, uint32_t rank, trt_band_copy* out) {
+    if (!out || ndev == 0 || rank >= ndev || width == 0) return fail(TRT_ERR_INVALID_ARG, "need 0 <= rank < ndev, a positive width and a result pointer");
+    band_copy_plan(width, height, ndev, rank, out);
+    return TRT_OK;
+}
+
 // ---- Sampler::sampling, batch form ----
 int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_sampled_color* out, uint32_t max_bounces,
                      trt_vec3 background, uint32_t seed, trt_stats* stats) {
@@ -707,64 +955,110 @@ int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_s
     const bool counting = stats != nullptr;
     ra.ref_tree = counting ? 1u : 0u;
     ra.leaf_slots = counting ? 1u : 4u;
+    int dev = 0;
+    TRT_HIP(hipGetDevice(&dev));
+    RenderCtx* c = nullptr;
+    rc = context_acquire(s, dev, 0, &c);
+    if (rc != TRT_OK) return rc;
     trt_sample_point* d_in = nullptr;
     trt_sampled_color* d_out = nullptr;
-    unsigned long long* d_ctr = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     unsigned long long h_ctr[CTR_COUNT] = {0};
     float ms = 0.0f;
-    auto cleanup = [&]() {
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
+    auto finish = [&](int code) {
+        (void)hipStreamSynchronize(c->stream);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
-        if (d_ctr) (void)hipFree(d_ctr);
+        (void)hipGetLastError();
+        context_release(s, dev, c);
+        return code;
     };
-    TRT_HIP_C(hipEventCreate(&ev0));
-    TRT_HIP_C(hipEventCreate(&ev1));
+#define TRT_HIP_C(call)                                                          \
+    do {                                                                         \
+        hipError_t e_ = (call);                                                  \
+        if (e_ != hipSuccess) return finish(fail_hip(e_, #call));                \
+    } while (0)
     TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * sizeof(trt_sample_point)));
     TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * sizeof(trt_sampled_color)));
-    TRT_HIP_C(hipMalloc(reinterpret_cast<void**>(&d_ctr), sizeof(h_ctr)));
-    TRT_HIP_C(hipMemset(d_ctr, 0, sizeof(h_ctr)));
-    TRT_HIP_C(hipMemcpy(d_in, in, (size_t)n * sizeof(trt_sample_point), hipMemcpyHostToDevice));
-    TRT_HIP_C(hipEventRecord(ev0, nullptr));
-    TRT_HIP_C(launch_sample_batch(sc, d_in, n, d_out, ra, d_ctr, counting, nullptr));
-    TRT_HIP_C(hipEventRecord(ev1, nullptr));
-    TRT_HIP_C(hipMemcpy(out, d_out, (size_t)n * sizeof(trt_sampled_color), hipMemcpyDeviceToHost));
-    TRT_HIP_C(hipMemcpy(h_ctr, d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost));
-    TRT_HIP_C(hipEventElapsedTime(&ms, ev0, ev1));
-    cleanup();
+    TRT_HIP_C(hipMemsetAsync(c->d_ctr, 0, sizeof(h_ctr), c->stream));
+    TRT_HIP_C(hipMemcpyAsync(d_in, in, (size_t)n * sizeof(trt_sample_point), hipMemcpyHostToDevice, c->stream));
+    TRT_HIP_C(hipEventRecord(c->ev0, c->stream));
+    TRT_HIP_C(launch_sample_batch(sc, d_in, n, d_out, ra, c->d_ctr, counting, c->stream));
+    TRT_HIP_C(hipEventRecord(c->ev1, c->stream));
+    TRT_HIP_C(hipMemcpyAsync(out, d_out, (size_t)n * sizeof(trt_sampled_color), hipMemcpyDeviceToHost, c->stream));
+    TRT_HIP_C(hipMemcpyAsync(h_ctr, c->d_ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, c->stream));
+    TRT_HIP_C(hipStreamSynchronize(c->stream));
+    TRT_HIP_C(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+#undef TRT_HIP_C
+    (void)finish(TRT_OK);
     if (stats) { counters_to_stats(h_ctr, stats); stats->kernel_ms = ms; }
     return TRT_OK;
-#undef TRT_HIP_C
 }
 
 uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows) { return streamed_chunk_spp(width, rows); }
 
+// How the streamed backend would launch this render (host arithmetic only: works without a GPU).
+int trt_streamed_launch_plan(const trt_scene* s, const trt_camera* cam, const trt_render_params* p, trt_launch_plan* out) {
+    if (!s || !cam || !p || !out) return fail(TRT_ERR_INVALID_ARG, "null argument");
+    RenderArgs ra;
+    uint32_t rows = 0;
+    int rc = to_render_args(cam, p, ra, rows);
+    if (rc != TRT_OK) return rc;
+    const StreamLaunchPlan pl = streamed_launch_plan(s->host.layout, ra, p->collect_stats != 0);
+    memset(out, 0, sizeof(*out));
+    out->scene_mode = (uint32_t)pl.mode;
+    out->threads_per_workgroup = (uint32_t)pl.threads;
+    out->waves_per_simd = (uint32_t)pl.waves_per_simd;
+    out->workgroups_per_cu = pl.wg_per_cu;
+    out->lds_bytes = (uint32_t)pl.lds_bytes;
+    out->scene_lds_bytes = (uint32_t)pl.scene_lds_bytes;
+    out->leaf_slots = pl.slots;
+    out->lds_leaf_stack = pl.lds_stack ? 1u : 0u;
+    out->ray_pool = pl.pool ? 1u : 0u;
+    out->walk = (uint32_t)pl.walk;
+    out->specialised = pl.specialised ? 1u : 0u;
+    out->has_kernel = pl.kernel != nullptr ? 1u : 0u;
+    out->kernel_waves_per_simd = (uint32_t)pl.kernel_minw;
+    out->kernel_threads = (uint32_t)pl.kernel_threads;
+    out->kernel_walk = (uint32_t)pl.kernel_walk;
+    out->kernel_ray_pool = pl.kernel_pool ? 1u : 0u;
+    out->kernel_counting = pl.kernel_stats ? 1u : 0u;
+    out->chunk_spp = streamed_chunk_spp(cam->width, rows);
+    out->workspace_bytes = streamed_workspace_bytes(cam->width, rows);
+    return TRT_OK;
+}
+
 int trt_kernel_timing_begin(void) {
     std::lock_guard<std::mutex> lock(trt::g_timing_mu);
-    for (hipEvent_t ev : trt::g_timing_events) (void)hipEventDestroy(ev);
-    trt::g_timing_events.clear();
+    for (const trt::TimingPair& pr : trt::g_timing_pairs) { (void)hipEventDestroy(pr.begin); (void)hipEventDestroy(pr.end); }
+    trt::g_timing_pairs.clear();
+    trt::g_timing_epoch++;
     trt::g_timing_on = true;
     return TRT_OK;
 }
 int trt_kernel_timing_end(double* total_ms, uint32_t* launches) {
-    std::lock_guard<std::mutex> lock(trt::g_timing_mu);
-    trt::g_timing_on = false;
+    std::vector<trt::TimingPair> pairs;
+    {
+        std::lock_guard<std::mutex> lock(trt::g_timing_mu);
+        trt::g_timing_on = false;
+        pairs.swap(trt::g_timing_pairs);
+    }
     double sum = 0.0;
     uint32_t n = 0;
     int rc = TRT_OK;
-    std::vector<hipEvent_t>& evs = trt::g_timing_events;
-    for (size_t k = 0; k + 1 < evs.size(); k += 2) {
+    int prev = 0;
+    const bool have_prev = hipGetDevice(&prev) == hipSuccess;
+    for (const trt::TimingPair& pr : pairs) {
         float ms = 0.0f;
-        hipError_t e = hipEventSynchronize(evs[k + 1]);
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, evs[k], evs[k + 1]);
-        if (e != hipSuccess) { rc = fail_hip(e, "kernel timing events"); break; }
+        hipError_t e = hipSetDevice(pr.device);
+        if (e == hipSuccess) e = hipEventSynchronize(pr.end);
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, pr.begin, pr.end);
+        if (e != hipSuccess) { if (rc == TRT_OK) rc = fail_hip(e, "kernel timing events"); continue; }
         sum += ms;
         n++;
     }
-    for (hipEvent_t ev : evs) (void)hipEventDestroy(ev);
-    evs.clear();
+    for (const trt::TimingPair& pr : pairs) { (void)hipEventDestroy(pr.begin); (void)hipEventDestroy(pr.end); }
+    if (have_prev) (void)hipSetDevice(prev);
+    (void)hipGetLastError();
     if (total_ms) *total_ms = sum;
     if (launches) *launches = n;
     return rc;

@@ -77,6 +77,21 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
 uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows);   // samples per pixel per sample/fold launch pair (bounds the radiance buffer)
 size_t streamed_workspace_bytes(uint32_t width, uint32_t rows);
 const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra);
+// How launch_streamed runs a scene with these settings (streamed.hip; also what trt_streamed_launch_plan reports).  The
+// kernel's view of its dynamic LDS - scene copy | leaf stack (threads x slots x 8 B) | ray pool (36 B per lane) - is fixed
+// here and nowhere else; launch_streamed refuses a plan whose parts do not add up (hipErrorInvalidConfiguration).
+struct StreamLaunchPlan {
+    int mode, threads, waves_per_simd;      // scene mode, lanes per workgroup, waves per SIMD the grid is sized for
+    uint32_t wg_per_cu, slots;              // resident workgroups per CU; postponed-leaf slots per lane
+    bool lds_stack, flat, compact, pool, specialised;
+    int walk;                               // WALK_* the kernel will run
+    size_t lds_bytes, scene_lds_bytes;      // dynamic LDS per workgroup; the scene copy's share of it
+    const void* kernel;                     // the instantiation (nullptr: none - a bug, launch_streamed fails)
+    int kernel_minw, kernel_threads, kernel_walk;      // its template arguments (launch bound, lanes, WALK_RUNTIME = chooses at run time)
+    bool kernel_pool, kernel_stats;
+    const char* kernel_name;
+};
+StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra, bool stats);
 hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
                            unsigned long long* d_counters, bool stats, hipStream_t stream);
 

@@ -437,136 +437,13 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
     }
 }
 
-// A primitive's own hit distance on [kTMin, limit): what Sphere::hit / Quad::hit return for that interval, without
-// touching the walk's state.  Returns false on a miss.
-template <int MODE, bool STATS>
-TRT_DEV bool leaf_hit_t(const SceneAcc<MODE>& sc, const Ray& ray, uint32_t leaf, float limit, float& t_out, Counters<STATS>& ctr) {
-    const uint32_t idx = leaf & PRIM_INDEX_MASK;
-    if (leaf & PRIM_QUAD_BIT) {                                        // Quad::hit, quad.rs:33-54
-        if constexpr (STATS) ctr.quad_plane++;
-        float4 q0 = sc.quad(0, idx);
-        V3 nrm = v3(q0.x, q0.y, q0.z);
-        float dir_norm = dot(ray.d, nrm);
-        float t = (q0.w - dot(ray.o, nrm)) / dir_norm;
-        if (!(kTMin <= t && t < limit)) return false;
-        if constexpr (STATS) ctr.quad_inside++;
-        float4 q1 = sc.quad(1, idx), q2 = sc.quad(2, idx), q3 = sc.quad(3, idx), q4 = sc.quad(4, idx);
-        V3 p = ray_at(ray, t) - v3(q1.x, q1.y, q1.z);
-        V3 vv = v3(q2.x, q2.y, q2.z), ww = v3(q2.w, q3.x, q3.y), uu = v3(q3.z, q3.w, q4.x);
-        float planar_x = dot(cross(p, vv), ww);
-        float planar_y = dot(cross(uu, p), ww);
-        if (!(0.0f <= planar_x && planar_x < 1.0f && 0.0f <= planar_y && planar_y < 1.0f)) return false;
-        t_out = t;
-        return true;
-    }
-    if constexpr (STATS) ctr.sphere++;
-    return sphere_test(sc.sphere(idx), ray, kTMin, limit, t_out);      // Sphere::hit, sphere.rs:29-54
-}
-
-// OPT-IN (TRT_ORDERED_WALK=1): near-first walk for sphere-only scenes in global memory.
-// `nodes16` is this ray's octant array of a free-order SAH tree: pre-order with the child that is nearer along the split
-// axis first, 16-byte nodes as in walk_compact.  Visiting order does not matter for the result, because the result is
-// defined without it:
-//   the hit is the primitive with the smallest own hit distance, ties going to the smaller leaf sequence number,
-// which IS the reference's answer whenever that winner is "safe" - its distance not below the entry of its own exact
-// leaf box (tests/native/ordered_theorem_check.c) - "primitive" meaning one the reference can reach at all (exact
-// leaf box with t_far > start).  The walk keeps that arg-min over what it visits:
-//   * a box is culled against the best SAFE candidate's distance t_cull, and only if its entry lies beyond
-//     t_cull + eps / |d_j|, j = the axis of the box's entry plane, eps = min(kOrderedGap * D, kOrderedGapR * D^2 / r_min),
-//     D = the largest |box plane - origin| of the box.  A sphere's reported hit point satisfies the sphere's equation up to the
-//     backward error of the float evaluation, | |P - c|^2 - r^2 | <= ~24u (|o - c| + r)^2, so it lies within eps of the
-//     ball, hence of every box above it, and such a box is entered at most eps / |d_j| later: everything culled has
-//     an own distance strictly above t_cull and cannot be the arg-min, whatever its place in the reference's order;
-//   * a candidate replaces the best on smaller t, or equal t and smaller sequence number;
-//   * the function returns false for the (rounding-level rare) ray whose winner is unsafe; the caller re-traces it
-//     with the fixed-order walk.
-// Opt-in this round: the backward-error constant is a hand derivation (measured margin: hit points at most 7e-5 D
-// outside their box in 2.4e7 tangent-aimed rays, against 5.5e-3 D allowed).  Measured: bit-identical to the fixed-order
-// walk on every scene tried, including 6.6e9 rays of the 100 k touching-spheres scene (with a plain strict cull, 48 of
-// 2.6e7 rays differed).  Quads (grazing plane distances) have no such bound: scenes with quads keep walk_compact.
-constexpr float kOrderedGap = 5.5e-3f;        // see walk_ordered: worst distance of a false sphere hit from its box, per unit of D
-constexpr float kOrderedGapR = 9.0e-6f;       // the same per unit of D^2 / r (spheres of radius >= r)
-
-template <int MODE, bool STATS>
-TRT_DEV bool walk_ordered(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
-                          const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
-    const uint32_t n = sc.L.n_ordered_nodes;
-    uint32_t seq_best = 0xFFFFFFFFu;
-    bool safe_best = true;
-    float t_cull = __builtin_inff();                                                        // best safe candidate
-    // a point up to eps outside a box is followed by the box entry at most eps / |d_j| later, j = the axis whose near
-    // plane is the entry (the other slabs were entered before); eps is the smaller of kOrderedGap * D (any radius)
-    // and kOrderedGapR * D^2 / r_min (the residual bound divided by 2r)
-    const V3 ainv = v3(__builtin_fabsf(tr.inv.x), __builtin_fabsf(tr.inv.y), __builtin_fabsf(tr.inv.z));
-    const float gap_r = sc.L.inv_r_min > 0.0f ? kOrderedGapR * sc.L.inv_r_min : __builtin_inff();
-    tr.i = 0u;
-    // does the box [lo, hi] pass: the ray crosses it (t_far >= start; `strict`: > as the reference needs for a leaf) and
-    // its entry is not beyond t_cull by more than the worst unsafety of anything inside it
-    auto box_passes = [&](V3 lo, V3 hi, bool strict, float& start_out) {
-        const V3 dl = lo - ray.o, dh = hi - ray.o;
-        const float dmax = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(dl.x), __builtin_fabsf(dh.x)),
-                                                           __builtin_fmaxf(__builtin_fabsf(dl.y), __builtin_fabsf(dh.y))),
-                                           __builtin_fmaxf(__builtin_fabsf(dl.z), __builtin_fabsf(dh.z)));
-        const float x0 = dl.x * tr.inv.x, x1 = dh.x * tr.inv.x, y0 = dl.y * tr.inv.y, y1 = dh.y * tr.inv.y, z0 = dl.z * tr.inv.z, z1 = dh.z * tr.inv.z;
-        const float nx = __builtin_fminf(x0, x1), ny = __builtin_fminf(y0, y1), nz = __builtin_fminf(z0, z1);
-        const float tn = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz);
-        const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(x0, x1), __builtin_fmaxf(y0, y1)), __builtin_fmaxf(z0, z1));
-        const float start = __builtin_fmaxf(kTMin, tn);
-        start_out = start;
-        const bool crosses = strict ? tf > start : !(tf < start);
-        const float inv_entry = tn == nx ? ainv.x : (tn == ny ? ainv.y : ainv.z);
-        const float eps = __builtin_fminf(kOrderedGap * dmax, gap_r * dmax * dmax);
-        return crosses && !(start > t_cull + eps * inv_entry);
-    };
-    for (;;) {
-        uint32_t cnt = 0;
-        while (tr.i < n && cnt < slots) {
-            const uint4 q = nodes16[tr.i];
-            if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
-            const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
-            float start;
-            const bool pass = box_passes(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), false, start);
-            const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
-            if (pass && is_leaf) {
-                stk[64u * cnt] = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), 0.0f);
-                cnt++;
-            }
-            tr.i = (pass || is_leaf) ? tr.i + 1u : q.w;
-        }
-        if (cnt == 0u) break;
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t seq = __float_as_uint(stk[64u * k].x);
-            const float4 na = leaf_list[2u * seq], nb = leaf_list[2u * seq + 1u];
-            if constexpr (STATS) ctr.node++;
-            float start;
-            if (box_passes(v3(na.x, na.y, na.z), v3(na.w, nb.x, nb.y), true, start)) {     // exact leaf box: reachable, and not safely beyond
-                if constexpr (STATS) { if (first_active_lane()) ctr.w_leaf++; }
-                // own hit distance up to and including the best so far (next float above it as the exclusive limit)
-                const float limit = tr.t_best < __builtin_inff() ? __uint_as_float(__float_as_uint(tr.t_best) + 1u) : tr.t_best;
-                float t;
-                if (leaf_hit_t<MODE, STATS>(sc, ray, __float_as_uint(nb.w), limit, t, ctr)) {
-                    const bool safe = t >= start;
-                    if (safe) t_cull = __builtin_fminf(t_cull, t);
-                    if (t < tr.t_best || seq < seq_best) {                               // t <= t_best here; equal t: the earlier leaf wins
-                        tr.t_best = t;
-                        tr.prim_best = __float_as_uint(nb.w);
-                        seq_best = seq;
-                        safe_best = safe;
-                    }
-                }
-            }
-        }
-    }
-    return safe_best;
-}
-
 constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)
 
 // Which walk a kernel instantiation runs.  WALK_RUNTIME picks by the launch arguments (every knob combination; counting
 // kernels); the others fix the walk at compile time, which is what the production launches use: the kernel then holds ONE
 // walk instead of five, with the SGPRs, VGPRs and instruction-cache footprint of one (stream_pool_kernel on Cornell:
 // 6849 lines of ISA, 44 spilled SGPRs and 16 spilled VGPRs with the runtime choice).
-enum { WALK_RUNTIME = 0, WALK_LDS_STACK = 1, WALK_FLAT = 2, WALK_COMPACT = 3, WALK_ORDERED = 4, WALK_REGS = 5 };
+enum { WALK_RUNTIME = 0, WALK_LDS_STACK = 1, WALK_FLAT = 2, WALK_COMPACT = 3, WALK_REGS = 5 };
 
 // Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  Postponed leaves go to
 // `lds_stack` (this lane's slot 0 of a `leaf_slots`-deep LDS stack) if the kernel has one, else into registers:
@@ -574,16 +451,10 @@ enum { WALK_RUNTIME = 0, WALK_LDS_STACK = 1, WALK_FLAT = 2, WALK_COMPACT = 3, WA
 template <int MODE, bool STATS, int WALK = WALK_RUNTIME>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
                              uint32_t leaf_slots = 4u, float2* lds_stack = nullptr, const float4* __restrict__ leaf_list = nullptr,
-                             const uint4* __restrict__ nodes16 = nullptr, const uint4* __restrict__ ordered16 = nullptr) {
+                             const uint4* __restrict__ nodes16 = nullptr) {
     Trav tr = trav_begin(sc, ray, ref_tree);
     if (__builtin_expect(!tr.ref, 1)) {
-        if constexpr (WALK == WALK_ORDERED) {
-            const uint32_t octant = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
-            if (!walk_ordered<MODE, STATS>(sc, ordered16 + (size_t)octant * sc.L.n_ordered_nodes, leaf_list, ray, tr, ctr, lds_stack, leaf_slots)) {
-                tr = trav_begin(sc, ray, ref_tree);                                     // unsafe winner: the fixed-order walk decides
-                walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
-            }
-        } else if constexpr (WALK == WALK_COMPACT) {
+        if constexpr (WALK == WALK_COMPACT) {
             walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
         } else if constexpr (WALK == WALK_FLAT) {
             walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
@@ -592,13 +463,7 @@ TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_
         } else if constexpr (WALK == WALK_REGS) {
             walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);
         } else {
-            if (lds_stack != nullptr && ordered16 != nullptr) {
-                const uint32_t octant = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
-                if (!walk_ordered<MODE, STATS>(sc, ordered16 + (size_t)octant * sc.L.n_ordered_nodes, leaf_list, ray, tr, ctr, lds_stack, leaf_slots)) {
-                    tr = trav_begin(sc, ray, ref_tree);                                 // unsafe winner: the fixed-order walk decides
-                    walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
-                }
-            } else if (lds_stack != nullptr && nodes16 != nullptr) walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
+            if (lds_stack != nullptr && nodes16 != nullptr) walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
             else if (lds_stack != nullptr && leaf_list != nullptr) walk_flat<MODE, STATS>(sc, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);
             else if (lds_stack != nullptr) walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots);
             else if (leaf_slots >= 4u || leaf_slots == 0u) walk_fast<MODE, STATS, 4>(sc, ray, tr, ctr);

@@ -68,8 +68,6 @@ struct World {
 //   [sphere_material: ns] u32   [material_kind: nm] u32          (padded to 16 bytes)   <- hot_bytes end here
 //   [reference nodes: 2n] same node format
 //   [leaf list: 2 per leaf] the leaves of the trees in walk order, same node format (skip = successor)
-//   [ordered tree: 8 x (2 n_leaves - 1)] scenes too large for LDS only: a free-order binned-SAH tree over the leaves, emitted
-//       once per ray-direction octant with the child that is nearer along the split axis first (rt_path.h walk_ordered)
 //   [compact culling tree: 1 per node] scenes too large for LDS only: (f16 lo.xy | lo.z,hi.x | hi.yz | skip or LEAF|k),
 //       boxes rounded OUTWARD to f16, pre-order (an inner node's first child is the next node)
 struct SceneLayout {
@@ -86,11 +84,8 @@ struct SceneLayout {
     uint32_t off_leaf_list;     // in 16-byte elements: the leaves alone, node format, skip = successor (cold part of the blob)
     uint32_t flat_walk;         // 1: few enough leaves that the streamed kernel steps the leaf list in lock-step (rt_path.h walk_flat)
     uint32_t off_compact;       // in 16-byte elements: the culling tree as 16-byte nodes (f16 boxes rounded outward), pre-order; 0 = absent
-    uint32_t off_ordered;       // in 16-byte elements: 8 pre-order arrays (one per ray-direction octant) of a free-order SAH tree, 16-byte nodes; 0 = absent
-    uint32_t n_ordered_nodes;   // nodes per octant array (2 * n_leaves - 1)
     uint32_t lazy_color;        // 1: every scattering material's albedo has |component| <= 1 (so a path's attenuation stays finite and
                                 //    `color += attenuation * 0` leaves colour at +0 until the path ends): kernels need not carry the colour
-    float inv_r_min;            // 1 / smallest sphere radius (0 if that radius is not positive): tightens walk_ordered's culling band
 };
 // Largest hot blob (SceneLayout::hot_bytes) copied whole into LDS, once per workgroup; larger scenes are read from global memory.
 constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;

@@ -212,119 +212,6 @@ struct CullBuilder {
 };
 
 
-// Free-order tree for the near-first walk (rt_path.h walk_ordered): top-down binned SAH over the leaf boxes (the
-// reference's leaves; their sequence numbers are what leaf nodes carry).  Any hierarchy of conservative boxes over any
-// order of the leaves will do - exactness comes from the arg-min rule, the strict cull and the safe-winner check
-//  - so this is free to minimise expected box tests.
-struct OrderedBuilder {
-    struct Node { Box box; int32_t left, right, leaf; uint32_t axis, size; };
-    const std::vector<Box>& leaf_box;
-    std::vector<Node> nodes;
-    std::vector<uint32_t> idx;
-
-    explicit OrderedBuilder(const std::vector<Box>& lb) : leaf_box(lb) {}
-
-    static double centroid(const Box& b, int a) { return 0.5 * ((double)(a == 0 ? b.lo.x : a == 1 ? b.lo.y : b.lo.z) + (double)(a == 0 ? b.hi.x : a == 1 ? b.hi.y : b.hi.z)); }
-
-    int32_t build_range(uint32_t a, uint32_t b, uint32_t depth = 0) {     // [a, b) of idx; returns node index
-        const int32_t me = (int32_t)nodes.size();
-        nodes.push_back(Node{});
-        Box all = leaf_box[idx[a]];
-        for (uint32_t k = a + 1; k < b; k++) all = box_union(all, leaf_box[idx[k]]);
-        nodes[(size_t)me].box = all;
-        nodes[(size_t)me].leaf = -1;
-        nodes[(size_t)me].axis = 0;
-        if (b - a == 1) { nodes[(size_t)me].leaf = (int32_t)idx[a]; nodes[(size_t)me].left = nodes[(size_t)me].right = -1; nodes[(size_t)me].size = 1; return me; }
-        // binned SAH over the three axes
-        constexpr int kBins = 16;
-        double best_cost = 1e300;
-        int best_axis = -1;
-        double best_pos = 0.0;
-        for (int ax = 0; ax < 3 && depth < 48u; ax++) {          // beyond depth 48: median splits only (bounds the recursion)
-            double cmin = 1e300, cmax = -1e300;
-            for (uint32_t k = a; k < b; k++) { const double c = centroid(leaf_box[idx[k]], ax); if (c < cmin) cmin = c; if (c > cmax) cmax = c; }
-            if (!(cmax > cmin) || !std::isfinite(cmax - cmin)) continue;
-            Box bin_box[kBins];
-            uint32_t bin_n[kBins] = {0};
-            const double scale = kBins / (cmax - cmin);
-            for (uint32_t k = a; k < b; k++) {
-                int bi = (int)((centroid(leaf_box[idx[k]], ax) - cmin) * scale);
-                if (bi < 0) bi = 0;
-                if (bi >= kBins) bi = kBins - 1;
-                bin_box[bi] = bin_n[bi] ? box_union(bin_box[bi], leaf_box[idx[k]]) : leaf_box[idx[k]];
-                bin_n[bi]++;
-            }
-            Box suffix[kBins];
-            uint32_t suffix_n[kBins];
-            Box acc{};
-            uint32_t n_acc = 0;
-            for (int bi = kBins - 1; bi >= 0; bi--) {
-                if (bin_n[bi]) { acc = n_acc ? box_union(acc, bin_box[bi]) : bin_box[bi]; n_acc += bin_n[bi]; }
-                suffix[bi] = acc; suffix_n[bi] = n_acc;
-            }
-            Box pre{};
-            uint32_t n_pre = 0;
-            for (int bi = 0; bi + 1 < kBins; bi++) {              // split after bin bi
-                if (bin_n[bi]) { pre = n_pre ? box_union(pre, bin_box[bi]) : bin_box[bi]; n_pre += bin_n[bi]; }
-                if (n_pre == 0 || suffix_n[bi + 1] == 0) continue;
-                const double c = surface_area(pre) * n_pre + surface_area(suffix[bi + 1]) * suffix_n[bi + 1];
-                if (c < best_cost) { best_cost = c; best_axis = ax; best_pos = cmin + (bi + 1) / scale; }
-            }
-        }
-        uint32_t mid;
-        if (best_axis >= 0) {
-            auto it = std::partition(idx.begin() + a, idx.begin() + b, [&](uint32_t k) { return centroid(leaf_box[k], best_axis) < best_pos; });
-            mid = (uint32_t)(it - idx.begin());
-            if (mid == a || mid == b) best_axis = -1;             // numerical corner: fall through to the median split
-        }
-        if (best_axis < 0) {                                      // coincident centroids (or non-finite boxes): split the range in half
-            mid = a + (b - a) / 2;
-            best_axis = 0;
-        }
-        nodes[(size_t)me].axis = (uint32_t)best_axis;
-        const int32_t l = build_range(a, mid, depth + 1u);
-        const int32_t r = build_range(mid, b, depth + 1u);
-        nodes[(size_t)me].left = l;
-        nodes[(size_t)me].right = r;
-        nodes[(size_t)me].size = 1u + nodes[(size_t)l].size + nodes[(size_t)r].size;
-        return me;
-    }
-
-    void build() {
-        const uint32_t n = (uint32_t)leaf_box.size();
-        idx.resize(n);
-        for (uint32_t k = 0; k < n; k++) idx[k] = k;
-        nodes.reserve(2 * (size_t)n);
-        build_range(0, n);
-    }
-
-    // pre-order emission for one octant: bit a of `octant` set = the ray direction is negative along axis a, so the
-    // child with the larger centroids along a split axis a (the right one) is nearer and goes first
-    void emit(uint32_t octant, uint32_t* out) const {
-        struct Item { int32_t node; };
-        std::vector<int32_t> stack;
-        stack.push_back(0);
-        uint32_t at = 0;
-        while (!stack.empty()) {
-            const Node& nd = nodes[(size_t)stack.back()];
-            stack.pop_back();
-            const uint32_t lx = f32_to_f16_dir(nd.box.lo.x, false), ly = f32_to_f16_dir(nd.box.lo.y, false), lz = f32_to_f16_dir(nd.box.lo.z, false);
-            const uint32_t hx = f32_to_f16_dir(nd.box.hi.x, true), hy = f32_to_f16_dir(nd.box.hi.y, true), hz = f32_to_f16_dir(nd.box.hi.z, true);
-            out[4 * at + 0] = lx | ly << 16;
-            out[4 * at + 1] = lz | hx << 16;
-            out[4 * at + 2] = hy | hz << 16;
-            out[4 * at + 3] = nd.leaf >= 0 ? (0x80000000u | (uint32_t)nd.leaf) : at + nd.size;     // leaf sequence number, or skip
-            at++;
-            if (nd.leaf < 0) {
-                const bool right_first = ((octant >> nd.axis) & 1u) != 0u;
-                const int32_t first = right_first ? nd.right : nd.left, second = right_first ? nd.left : nd.right;
-                stack.push_back(second);
-                stack.push_back(first);
-            }
-        }
-    }
-};
-
 void dump_tree(NodeDump& d, const std::vector<Box>& boxes, const std::vector<int32_t>& prim_geo, const std::vector<int32_t>& skip) {
     const size_t n = boxes.size();
     d.bbox6.resize(6 * n);
@@ -426,27 +313,11 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
         L.off_compact = L.blob_bytes / 16u;
         L.blob_bytes += 16u * nc;
     }
-    L.off_ordered = 0u;
-    L.n_ordered_nodes = 0u;
-    // near-first walk (rt_path.h walk_ordered): OPT-IN (TRT_ORDERED_WALK=1), sphere-only scenes walked from global memory.
-    // Bit-identical to the fixed-order walk on every scene measured; opt-in until its culling band's derivation has been
-    // reviewed.
-    bool want_ordered = false;
-    if (const char* e = getenv("TRT_ORDERED_WALK")) want_ordered = want_compact && nq == 0u && atoi(e) != 0;
-    L.inv_r_min = 0.0f;
-    if (want_ordered) {
-        float r_min = INFINITY;
-        for (const F4& sp : spheres) { const float r = fabsf(sp.w); if (r < r_min) r_min = r; }
-        if (r_min > 0.0f && r_min < INFINITY) L.inv_r_min = 1.0f / r_min;
-        L.n_ordered_nodes = 2u * L.n_leaves - 1u;
-        L.off_ordered = L.blob_bytes / 16u;
-        L.blob_bytes += 8u * 16u * L.n_ordered_nodes;
-    }
     {   // every offset and size of the layout is 32 bits wide: refuse scenes that do not fit instead of wrapping around
         const uint64_t prims = (uint64_t)ns + 5ull * nq + nm;
         const uint64_t total = 16ull * (2ull * nc + prims) + 4ull * ((uint64_t)ns + nm) + 16ull                 // hot part
                                + 32ull * nn + 32ull * L.n_leaves                                                  // reference tree, leaf list
-                               + (want_compact ? 16ull * nc : 0ull) + (want_ordered ? 8ull * 16ull * (2ull * L.n_leaves - 1ull) : 0ull);
+                               + (want_compact ? 16ull * nc : 0ull);
         if (total > 0xFFFFFFFFull) { msg = "scene too large: the packed scene would exceed 4 GiB"; return false; }
     }
     L.all_finite = all_finite ? 1u : 0u;
@@ -520,11 +391,6 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
         std::vector<uint32_t> lplace(nl);
         for (uint32_t k = 0; k < nl; k++) { lskip[k] = (int32_t)k + 1; lplace[k] = k; }
         pack_nodes(f4 + L.off_leaf_list, leaf_box, lprim, lskip, lplace);
-    }
-    if (L.off_ordered) {
-        OrderedBuilder ob(leaf_box);
-        ob.build();
-        for (uint32_t o = 0; o < 8u; o++) ob.emit(o, u32 + 4u * ((size_t)L.off_ordered + (size_t)o * L.n_ordered_nodes));
     }
     if (L.off_compact) {   // compact culling tree: f16 boxes rounded outward (any superset box keeps the hits: DESIGN.md 4.1), pre-order
         uint32_t* c = u32 + 4u * (size_t)L.off_compact;

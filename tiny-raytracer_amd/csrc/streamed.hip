@@ -40,8 +40,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                                                                              unsigned long long* __restrict__ counters,
                                                                              uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp,
                                                                              const float4* __restrict__ leaf_list,
-                                                                             const uint4* __restrict__ nodes16,
-                                                                             const uint4* __restrict__ ordered16) {
+                                                                             const uint4* __restrict__ nodes16) {
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
     const uint32_t lane = threadIdx.x & 63u;
@@ -71,6 +70,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     Trav tr{};                                                                    // a walk under way (kResumable only)
     bool walking = false;
 
+    TRT_CLK_START(ctr);
     for (;;) {
         // ---- take items ahead: whenever a lane has neither a path nor a stocked ray, every lane without stock takes one ----
         if (!exhausted && __builtin_amdgcn_ballot_w64(!has_path && !stocked) != 0ull) {
@@ -122,6 +122,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if (exhausted) break;
             continue;                                                             // a batch of off-image items: fetch the next
         }
+        TRT_CLK(ctr, 0);
         if (has_path) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             if constexpr (kResumable) {
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             } else {
                 n_rays++;
                 float t;
-                const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
+                const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16);
                 if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
                     float* c = colors + 3ull * out_idx;
                     c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -148,6 +149,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                 }
             }
         }
+        TRT_CLK(ctr, 3);
     }
     flush_counters<STATS>(counters, n_samples, n_rays, ctr);
 }
@@ -172,8 +174,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                                                                            unsigned long long* __restrict__ counters,
                                                                            uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp,
                                                                            const float4* __restrict__ leaf_list,
-                                                                           const uint4* __restrict__ nodes16,
-                                                                           const uint4* __restrict__ ordered16) {
+                                                                           const uint4* __restrict__ nodes16) {
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
     const uint32_t lane = threadIdx.x & 63u;
@@ -279,7 +280,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
             } else {
                 n_rays++;
                 float t;
-                const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ordered16);
+                const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16);
                 if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
                     float* c = colors + 3ull * out_idx;
                     c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -308,12 +309,6 @@ __global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restric
     out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
 }
 
-// counting or plain variant at fixed scene mode / waves per SIMD / workgroup size
-template <int MODE, int MINW, int THREADS, typename Go>
-static hipError_t launch_pick(bool stats, Go&& go) {
-    return stats ? go(stream_sample_kernel<MODE, true, MINW, THREADS>) : go(stream_sample_kernel<MODE, false, MINW, THREADS>);
-}
-
 // Samples per pixel per sample/fold launch pair: as many as keep the radiance buffer near 4 GB (16..256).
 uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows) {
     const unsigned long long px = (unsigned long long)width * rows;
@@ -327,16 +322,67 @@ size_t streamed_workspace_bytes(uint32_t width, uint32_t rows) {
     return (size_t)width * rows * streamed_chunk_spp(width, rows) * 3 * sizeof(float) + 256;      // radiance buffer + batch counter
 }
 
-// How a scene is launched: workgroup shape, waves per SIMD, where the postponed leaves live, which walk, which kernel.
-struct StreamPlan {
-    int mode, threads, w;
-    uint32_t wg_per_cu, slots;
-    bool lds_stack, flat, compact, ordered, pool;
-    size_t lds_bytes;
-};
+namespace {
 
-static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) {
-    StreamPlan pl{};
+constexpr size_t kLdsPerCu = 160u * 1024u;
+inline size_t align16(size_t b) { return (b + 15u) & ~(size_t)15u; }
+
+// One kernel instantiation the launcher may pick.  Every instantiation has the same parameter list, so a launch is
+// hipLaunchKernel(fn, ...) with one argument array whichever entry is chosen.
+struct KernelEntry {
+    const void* fn;
+    int mode, threads, minw;        // template arguments: scene mode, lanes per workgroup, launch bound (waves per SIMD)
+    int walk;                       // WALK_RUNTIME: the kernel picks the walk from its arguments (every knob, counting variants)
+    bool pool, stats, lazy;
+};
+#define TRT_POOL(MODE, STATS, MINW, THREADS, WALK, LAZY) \
+    KernelEntry{reinterpret_cast<const void*>(&stream_pool_kernel<MODE, STATS, MINW, THREADS, WALK, LAZY>), MODE, THREADS, MINW, WALK, true, STATS, LAZY}
+#define TRT_SAMPLE(MODE, STATS, MINW, THREADS, WALK, LAZY) \
+    KernelEntry{reinterpret_cast<const void*>(&stream_sample_kernel<MODE, STATS, MINW, THREADS, WALK, LAZY>), MODE, THREADS, MINW, WALK, false, STATS, LAZY}
+
+// production launches: walk fixed at compile time, lazy colour, no counters
+const KernelEntry kSpecialised[] = {
+    TRT_POOL(MODE_LDS, false, 6, 256, WALK_FLAT, true),
+    TRT_POOL(MODE_LDS, false, 7, 256, WALK_FLAT, true),
+    TRT_POOL(MODE_LDS, false, 8, 256, WALK_FLAT, true),
+    TRT_POOL(MODE_LDS, false, 6, 256, WALK_LDS_STACK, true),
+    TRT_SAMPLE(MODE_LDS, false, 6, 512, WALK_REGS, true),
+    TRT_SAMPLE(MODE_LDS, false, 6, 768, WALK_LDS_STACK, true),
+    TRT_POOL(MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true),
+};
+// every other knob combination and the counting variants: runtime choice of the walk
+const KernelEntry kGeneral[] = {
+    TRT_SAMPLE(MODE_LDS, false, 6, 768, WALK_RUNTIME, false),    TRT_SAMPLE(MODE_LDS, true, 6, 768, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_LDS, false, 6, 512, WALK_RUNTIME, false),    TRT_SAMPLE(MODE_LDS, true, 6, 512, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_LDS, false, 5, 512, WALK_RUNTIME, false),    TRT_SAMPLE(MODE_LDS, true, 5, 512, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_LDS, false, 7, 256, WALK_RUNTIME, false),    TRT_SAMPLE(MODE_LDS, true, 7, 256, WALK_RUNTIME, false),
+    TRT_POOL(MODE_LDS, false, 6, 256, WALK_RUNTIME, false),      TRT_POOL(MODE_LDS, true, 6, 256, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_LDS, false, 6, 256, WALK_RUNTIME, false),    TRT_SAMPLE(MODE_LDS, true, 6, 256, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_LDS, false, 5, 256, WALK_RUNTIME, false),    TRT_SAMPLE(MODE_LDS, true, 5, 256, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_HYBRID, false, 1, 256, WALK_RUNTIME, false), TRT_SAMPLE(MODE_HYBRID, true, 1, 256, WALK_RUNTIME, false),
+    TRT_POOL(MODE_GLOBAL, false, 8, 256, WALK_RUNTIME, false),   TRT_POOL(MODE_GLOBAL, true, 8, 256, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_GLOBAL, false, 8, 256, WALK_RUNTIME, false), TRT_SAMPLE(MODE_GLOBAL, true, 8, 256, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_GLOBAL, false, 7, 256, WALK_RUNTIME, false), TRT_SAMPLE(MODE_GLOBAL, true, 7, 256, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_GLOBAL, false, 6, 256, WALK_RUNTIME, false), TRT_SAMPLE(MODE_GLOBAL, true, 6, 256, WALK_RUNTIME, false),
+    TRT_SAMPLE(MODE_GLOBAL, false, 1, 256, WALK_RUNTIME, false), TRT_SAMPLE(MODE_GLOBAL, true, 1, 256, WALK_RUNTIME, false),
+};
+#undef TRT_POOL
+#undef TRT_SAMPLE
+
+const KernelEntry* find_general(int mode, int threads, int minw, bool pool, bool stats) {
+    for (const KernelEntry& k : kGeneral)
+        if (k.mode == mode && k.threads == threads && k.minw == minw && k.pool == pool && k.stats == stats) return &k;
+    return nullptr;
+}
+
+}  // namespace
+
+// How a scene is launched: workgroup shape, waves per SIMD, where the postponed leaves live, which walk, which kernel.
+// Everything the kernel assumes about its LDS (scene copy | leaf stack: threads x slots x 8 bytes | ray pool: 36 bytes per lane)
+// is decided HERE and nowhere else; trt_streamed_launch_plan exposes the result, and the CPU tests check its invariants for
+// every scene size and every knob (tests/test_host_boundary.py).
+StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra_all, bool stats) {
+    StreamLaunchPlan pl{};
     const size_t scene_bytes = scene_lds_bytes(L);
     const int mode = scene_mode(L);
     // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies; a big LDS copy (> 20 KB) is shared by
@@ -346,18 +392,20 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
     // 8 waves per SIMD for scenes read from global memory
     int threads = 256;
     if (mode == MODE_LDS && L.hot_bytes > 20u * 1024u) {
-        threads = (((scene_bytes + 15u) & ~(size_t)15u) + 768u * 4u * sizeof(float2)) * 2u <= 160u * 1024u && ra_all.lds_leaf_stack != 0u ? 768 : 512;
+        threads = (align16(scene_bytes) + 768u * 4u * sizeof(float2)) * 2u <= kLdsPerCu && ra_all.lds_leaf_stack != 0u ? 768 : 512;
         if (const char* env = getenv("TRT_BIG_THREADS")) { const int t = atoi(env); if (t == 512 || t == 768) threads = t; }
     }
-    // LDS scenes: 6 waves per SIMD (80 VGPRs, 21 spilled) beat 7 (72 VGPRs, 38 spilled) by 3 % and 5 (no spills) by 2 % on
-    // Cornell.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box step once the
-    // compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6, 2.29 at 8)
+    // LDS scenes: 6 waves per SIMD.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box
+    // step once the compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6,
+    // 2.29 at 8)
     int w = mode == MODE_LDS ? 6 : 8;
     if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
     if (w < 5) w = 5;
+    if (w > 8) w = 8;
     if (threads == 512 && w > 6) w = 6;
     if (threads == 768) w = 6;
-    uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
+    if (mode == MODE_HYBRID) w = 1;                                               // one instantiation only (tuning knob TRT_TOP_NODES)
+    uint32_t wg_per_cu = mode == MODE_HYBRID ? 4u : (uint32_t)(w * 4 * 64 / threads);
     // slots of the LDS stack: 4 for tree walks; 7 for the lock-step leaf list, whose t_best stays stale for a whole walk
     // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12) and which steps two leaves per trip, so a lane must have two free
     const bool flat = L.flat_walk && !ra_all.ref_tree;
@@ -367,43 +415,77 @@ static StreamPlan plan_streamed(const SceneLayout& L, const RenderArgs& ra_all) 
         // the default depth gives way to occupancy: the deepest stack (<= 7, >= 4) with which stack + ray pool + scene copy of
         // all the CU's workgroups fit its 160 KB of LDS (Cornell: 7 slots at 6 waves per SIMD, 5 at 7, 4 at 8)
         const size_t pool_b = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-        while (slots > 4u && (((scene_bytes + 15u) & ~(size_t)15u) + (size_t)threads * slots * sizeof(float2) + pool_b) * wg_per_cu > 160u * 1024u) slots--;
+        while (slots > 4u && (align16(scene_bytes) + (size_t)threads * slots * sizeof(float2) + pool_b) * wg_per_cu > kLdsPerCu) slots--;
     }
     if (threads > 512 && ra_all.leaf_slots == 0u) {
-        while (slots > 3u && (((scene_bytes + 15u) & ~(size_t)15u) + (size_t)threads * slots * sizeof(float2)) * wg_per_cu > 160u * 1024u) slots--;
+        while (slots > 3u && (align16(scene_bytes) + (size_t)threads * slots * sizeof(float2)) * wg_per_cu > kLdsPerCu) slots--;
     }
     const size_t stack_bytes = (size_t)threads * slots * sizeof(float2);
-    const size_t with_stack = ((scene_bytes + 15u) & ~(size_t)15u) + stack_bytes;
+    const size_t with_stack = align16(scene_bytes) + stack_bytes;
     // LDS: scene copy + the postponed-leaf stack (8 bytes per lane and slot), the latter only where it does not cost a
     // resident workgroup (random-spheres: 49.6 KB scene copy, 3 workgroups of 512 lanes per CU without it, 2 with it:
     // measured 7 % slower than register slots); otherwise the slots are registers
-    bool lds_stack = ra_all.lds_leaf_stack != 0u;
+    bool lds_stack = ra_all.lds_leaf_stack != 0u && with_stack <= kLdsPerCu;
     if (lds_stack && ra_all.lds_leaf_stack != 2u) {
-        const uint32_t fit_plain = scene_bytes ? (uint32_t)(160u * 1024u / scene_bytes) : wg_per_cu;
-        const uint32_t fit_stack = (uint32_t)(160u * 1024u / with_stack);
+        const uint32_t fit_plain = scene_bytes ? (uint32_t)(kLdsPerCu / scene_bytes) : wg_per_cu;
+        const uint32_t fit_stack = (uint32_t)(kLdsPerCu / with_stack);
         lds_stack = (fit_stack < wg_per_cu ? fit_stack : wg_per_cu) >= (fit_plain < wg_per_cu ? fit_plain : wg_per_cu);
     }
     // few primitives: lock-step leaf list (rt_path.h walk_flat); scenes read from global memory: 16-byte culling nodes
-    // (walk_compact), on request walked near-first through a free-order tree (walk_ordered).  All need the LDS stack.
+    // (walk_compact).  Both need the LDS stack.
     const bool compact = lds_stack && mode == MODE_GLOBAL && L.off_compact != 0u && !ra_all.ref_tree;
     // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack and 256-lane workgroups (LDS scenes at 6
-    // waves per SIMD, global-memory scenes at 8), and must not cost a resident workgroup either
+    // waves per SIMD and more, global-memory scenes at 8), and must not cost a resident workgroup either
     const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
     bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && w == 8));
     if (const char* env = getenv("TRT_RAY_POOL")) pool = pool && atoi(env) != 0;
-    if (pool) pool = (uint32_t)(160u * 1024u / (with_stack + pool_bytes)) >= wg_per_cu;
+    if (pool) pool = (uint32_t)(kLdsPerCu / (with_stack + pool_bytes)) >= wg_per_cu;
+
+    // ---- the kernel instantiation ----
+    const int walk = compact ? WALK_COMPACT : (flat && lds_stack) ? WALK_FLAT : lds_stack ? WALK_LDS_STACK : WALK_REGS;
+    const bool slots_ok = lds_stack || ra_all.leaf_slots == 0u || ra_all.leaf_slots >= 4u;      // WALK_REGS has 4 register slots
+    const KernelEntry* k = nullptr;
+    if (!stats && slots_ok && L.lazy_color && getenv("TRT_RUNTIME_WALK") == nullptr) {
+        for (const KernelEntry& e : kSpecialised)
+            if (e.mode == mode && e.threads == threads && e.minw == w && e.pool == pool && e.walk == walk) { k = &e; break; }
+    }
+    pl.specialised = k != nullptr;
+    if (!k) {
+        // the general instantiations exist for fewer (waves, pool) combinations than the knobs can ask for: take the nearest one
+        // BELOW the request and make the plan follow the kernel, so that grid and LDS are sized for what really runs
+        bool kpool = pool;
+        int kw = w;
+        if (mode == MODE_LDS && threads == 256) {
+            if (w >= 7) { kw = 7; kpool = false; }                  // 7 waves: sample kernel only
+            else if (w == 6) kw = 6;
+            else { kw = 5; kpool = false; }
+        } else if (mode == MODE_LDS && threads == 512) { kw = w >= 6 ? 6 : 5; kpool = false; }
+        else if (mode == MODE_LDS) { kw = 6; kpool = false; }
+        else if (mode == MODE_HYBRID) { kw = 1; kpool = false; }
+        else {                                                      // MODE_GLOBAL
+            if (w >= 8) kw = 8;
+            else if (w == 7) { kw = 7; kpool = false; }
+            else if (w == 6) { kw = 6; kpool = false; }
+            else { kw = 1; kpool = false; }
+        }
+        k = find_general(mode, threads, kw, kpool, stats);
+        pool = kpool;
+        if (kw >= 5 && kw < w) { w = kw; wg_per_cu = (uint32_t)(w * 4 * 64 / threads); }
+    }
     const size_t lds_bytes = lds_stack ? with_stack + (pool ? pool_bytes : 0u) : scene_bytes;
-    if (lds_bytes) { const uint32_t by_lds = (uint32_t)(160u * 1024u / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
-    pl.mode = mode; pl.threads = threads; pl.w = w; pl.wg_per_cu = wg_per_cu; pl.slots = slots;
-    pl.lds_stack = lds_stack; pl.flat = flat && lds_stack; pl.compact = compact; pl.ordered = compact && L.off_ordered != 0u; pl.pool = pool;
-    pl.lds_bytes = lds_bytes;
+    if (lds_bytes) { const uint32_t by_lds = (uint32_t)(kLdsPerCu / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
+    pl.mode = mode; pl.threads = threads; pl.waves_per_simd = w; pl.wg_per_cu = wg_per_cu; pl.slots = slots;
+    pl.lds_stack = lds_stack; pl.flat = flat && lds_stack; pl.compact = compact; pl.pool = pool; pl.walk = walk;
+    pl.lds_bytes = lds_bytes; pl.scene_lds_bytes = scene_bytes;
+    pl.kernel = k ? k->fn : nullptr;
+    pl.kernel_minw = k ? k->minw : 0; pl.kernel_threads = k ? k->threads : 0; pl.kernel_walk = k ? k->walk : 0; pl.kernel_pool = k ? k->pool : false;
+    pl.kernel_stats = k ? k->stats : false;
+    pl.kernel_name = pool ? "trt::stream_pool_kernel" : "trt::stream_sample_kernel";
     return pl;
 }
 
 // Name of the kernel that dominates a streamed render of this scene (for profiles and bench.py's roofline line).
-const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra) {
-    return plan_streamed(L, ra).pool ? "trt::stream_pool_kernel" : "trt::stream_sample_kernel";
-}
+const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra) { return streamed_launch_plan(L, ra, false).kernel_name; }
 
 hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra_all, void* workspace, float* d_accum,
                            unsigned long long* d_counters, bool stats, hipStream_t stream) {
@@ -412,85 +494,51 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     float* colors = static_cast<float*>(workspace);
     const uint32_t chunk = streamed_chunk_spp(cam.width, ra_all.rows_local);
     uint32_t* batch_counter = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (size_t)n_pixels * chunk * 3 * sizeof(float));
-    const uint32_t tiles_x = (cam.width + 7u) / 8u, tiles_y = (ra_all.rows_local + 7u) / 8u;
-    const uint32_t n_tiles = tiles_x * tiles_y;
+    uint32_t tiles_x = (cam.width + 7u) / 8u;
+    const uint32_t tiles_y = (ra_all.rows_local + 7u) / 8u;
+    uint32_t n_tiles = tiles_x * tiles_y;
     int dev = 0, cus = 256;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const StreamPlan pl = plan_streamed(sc.L, ra_all);
-    const int mode = pl.mode, threads = pl.threads, w = pl.w;
-    const uint32_t wg_per_cu = pl.wg_per_cu, slots = pl.slots;
-    const bool lds_stack = pl.lds_stack, pool = pl.pool;
-    const size_t lds_bytes = pl.lds_bytes;
+    const StreamLaunchPlan pl = streamed_launch_plan(sc.L, ra_all, stats);
+    if (pl.kernel == nullptr) return hipErrorInvalidDeviceFunction;               // no instantiation for this plan: a bug, never a fallback
+    // the kernel's assumptions about its dynamic LDS, checked where the launch is made (scene copy | leaf stack | ray pool)
+    {
+        size_t need = pl.scene_lds_bytes;
+        if (pl.lds_stack) need = align16(need) + (size_t)pl.threads * pl.slots * sizeof(float2) + (pl.pool ? (size_t)pl.threads * kPoolDwords * sizeof(uint32_t) : 0u);
+        if (need != pl.lds_bytes || pl.lds_bytes > kLdsPerCu || pl.kernel_threads != pl.threads || (pl.pool && !pl.lds_stack) ||
+            (pl.flat && pl.slots < 2u) || (pl.kernel_pool != pl.pool)) return hipErrorInvalidConfiguration;
+    }
+    SceneDev scd = sc;
+    CameraDev camd = cam;
     const float4* leaf_list = (pl.flat || pl.compact) ? sc.blob + sc.L.off_leaf_list : nullptr;
     const uint4* nodes16 = pl.compact ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_compact) : nullptr;
-    const uint4* ordered16 = pl.ordered ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_ordered) : nullptr;
-    const uint32_t resident = (uint32_t)cus * wg_per_cu;
-    const uint32_t waves_per_wg = (uint32_t)threads / 64u;
+    const uint32_t resident = (uint32_t)cus * pl.wg_per_cu;
+    const uint32_t waves_per_wg = (uint32_t)pl.threads / 64u;
+    if (pl.lds_bytes > 48u * 1024u) {
+        e = hipFuncSetAttribute(pl.kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return e;
+    }
     bool first = true;
     for (uint32_t s0 = ra_all.sample_begin; s0 < ra_all.sample_end; s0 += chunk) {
         RenderArgs ra = ra_all;
-        ra.lds_leaf_stack = lds_stack ? 1u : 0u;
-        if (lds_stack) ra.leaf_slots = slots;
+        ra.lds_leaf_stack = pl.lds_stack ? 1u : 0u;
+        if (pl.lds_stack) ra.leaf_slots = pl.slots;
         ra.sample_begin = s0;
         ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;
         uint32_t batch_spp = kBatchSpp;
         if (const char* env = getenv("TRT_STREAM_BATCH_SPP")) batch_spp = (uint32_t)atoi(env) ? (uint32_t)atoi(env) : kBatchSpp;
-        const uint32_t n_batches = n_tiles * ((ra.sample_end - ra.sample_begin + batch_spp - 1u) / batch_spp);
+        uint32_t n_batches = n_tiles * ((ra.sample_end - ra.sample_begin + batch_spp - 1u) / batch_spp);
         uint32_t grid_x = resident;
         const uint32_t max_useful = (n_batches + waves_per_wg - 1u) / waves_per_wg;   // one batch per wave at least
         if (grid_x > max_useful) grid_x = max_useful ? max_useful : 1u;
-        const dim3 grid(grid_x), block((uint32_t)threads);
         e = hipMemsetAsync(batch_counter, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
-        auto go = [&](auto kernel) -> hipError_t {
-            if (lds_bytes > 48u * 1024u) {
-                hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-                if (e2 != hipSuccess) return e2;
-            }
-            timing_mark(stream, true);
-            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, sc, cam, ra, colors, batch_counter, d_counters, tiles_x, n_tiles, n_batches, batch_spp, leaf_list, nodes16, ordered16);
-            const hipError_t le = hipGetLastError();
-            timing_mark(stream, false);
-            return le;
-        };
-        // production defaults run kernels with the walk fixed at compile time; every other knob combination and the counting
-        // variants run the runtime-dispatch instantiations below
-        const int walk = pl.ordered ? WALK_ORDERED : pl.compact ? WALK_COMPACT : pl.flat ? WALK_FLAT : lds_stack ? WALK_LDS_STACK : WALK_REGS;
-        const bool slots_ok = lds_stack || ra_all.leaf_slots == 0u || ra_all.leaf_slots >= 4u;      // WALK_REGS has 4 register slots
-        bool specialised = !stats && slots_ok && sc.L.lazy_color && getenv("TRT_RUNTIME_WALK") == nullptr;
-        if (specialised) {
-            if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_FLAT, true>);
-            else if (mode == MODE_LDS && threads == 256 && w == 7 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 7, 256, WALK_FLAT, true>);
-            else if (mode == MODE_LDS && threads == 256 && w >= 8 && pool && walk == WALK_FLAT) e = go(stream_pool_kernel<MODE_LDS, false, 8, 256, WALK_FLAT, true>);
-            else if (mode == MODE_LDS && threads == 256 && w == 6 && pool && walk == WALK_LDS_STACK) e = go(stream_pool_kernel<MODE_LDS, false, 6, 256, WALK_LDS_STACK, true>);
-            else if (mode == MODE_LDS && threads == 512 && w == 6 && walk == WALK_REGS) e = go(stream_sample_kernel<MODE_LDS, false, 6, 512, WALK_REGS, true>);
-            else if (mode == MODE_LDS && threads == 768 && walk == WALK_LDS_STACK && !pool) e = go(stream_sample_kernel<MODE_LDS, false, 6, 768, WALK_LDS_STACK, true>);
-            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_COMPACT) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true>);
-            else if (mode == MODE_GLOBAL && w >= 8 && pool && walk == WALK_ORDERED) e = go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256, WALK_ORDERED, true>);
-            else specialised = false;
-        }
-        if (!specialised) switch (mode) {
-            case MODE_LDS:
-                if (threads == 768) e = launch_pick<MODE_LDS, 6, 768>(stats, go);
-                else if (threads == 512) {
-                    if (w >= 6) e = launch_pick<MODE_LDS, 6, 512>(stats, go);
-                    else e = launch_pick<MODE_LDS, 5, 512>(stats, go);
-                } else if (w >= 7) e = launch_pick<MODE_LDS, 7, 256>(stats, go);
-                else if (w == 6 && pool) e = stats ? go(stream_pool_kernel<MODE_LDS, true, 6, 256>) : go(stream_pool_kernel<MODE_LDS, false, 6, 256>);
-                else if (w == 6) e = launch_pick<MODE_LDS, 6, 256>(stats, go);
-                else e = launch_pick<MODE_LDS, 5, 256>(stats, go);
-                break;
-            case MODE_HYBRID: e = launch_pick<MODE_HYBRID, 1, 256>(stats, go); break;
-            default:
-                if (w >= 8 && pool) e = stats ? go(stream_pool_kernel<MODE_GLOBAL, true, 8, 256>) : go(stream_pool_kernel<MODE_GLOBAL, false, 8, 256>);
-                else if (w >= 8) e = launch_pick<MODE_GLOBAL, 8, 256>(stats, go);
-                else if (w >= 7) e = launch_pick<MODE_GLOBAL, 7, 256>(stats, go);
-                else if (w >= 6) e = launch_pick<MODE_GLOBAL, 6, 256>(stats, go);
-                else e = launch_pick<MODE_GLOBAL, 1, 256>(stats, go);
-                break;
-        }
+        void* args[] = {&scd, &camd, &ra, &colors, &batch_counter, &d_counters, &tiles_x, &n_tiles, &n_batches, &batch_spp, &leaf_list, &nodes16};
+        timing_mark(stream, true);
+        e = hipLaunchKernel(pl.kernel, dim3(grid_x), dim3((uint32_t)pl.threads), args, pl.lds_bytes, stream);
+        timing_mark(stream, false);
         if (e != hipSuccess) return e;
         const uint32_t fold_blocks = (uint32_t)((n_pixels + 255ull) / 256ull);
         hipLaunchKernelGGL(stream_fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, colors, d_accum, n_pixels, ra.sample_end - ra.sample_begin,

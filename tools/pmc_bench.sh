@@ -43,6 +43,7 @@ for f in glob.glob(base + "/trace/*/*_kernel_stats.csv"):
     open(f"gpurun_out/prof_keep/{tag}_kernel_stats.csv", "w").write(open(f).read())
 line = json.loads(open(base + "/trace.json").read().strip().splitlines()[-1])
 out["pmc_key"] = line["roofline"]["pmc_key"]
+out["rays_per_launch"] = line["roofline"]["rays_per_launch"]      # bench.py scales the per-launch counts by rays (any N, any share of the frame)
 out["kernel_source_digest"] = b.kernel_source_digest()
 # gfx950 (guides/MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB; FETCH_SIZE tallies 128-byte requests at 64 B -> x2
 out["hbm_bytes_per_launch"] = (2.0 * out.get("FETCH_SIZE", 0.0) + out.get("WRITE_SIZE", 0.0)) * 1024.0

@@ -1,7 +1,22 @@
 #!/bin/bash
 # The GPU parity suite once per fallback path (every knob below changes scheduling or layout only; frames must not move).
 # TRT_RUNTIME_WALK=1: the kernels that choose the walk at run time instead of the ones specialised at compile time.
+#
+# Every knob's FULL output is kept (gpurun_out/knobs/<knob>.log), pytest runs under -X faulthandler (a host SIGSEGV / SIGABRT
+# leaves the Python stack of every thread in the log), HIP runtime errors are logged (AMD_LOG_LEVEL=1) and a GPU memory fault
+# leaves the runtime's own "Memory access fault by GPU node ..." line there too: one normal pass records WHAT a failure was.
+# (Round 2's version piped pytest through `tail -1` and lost exactly that when `TRT_STREAM_MINW=8` dumped core once.)
+# The script stops at the first knob that does not pass: after a fault, no further GPU work in the same call.
+out=gpurun_out/knobs; mkdir -p $out
+skip='not leaf_slots_are and not lockstep and not global_memory_walks and not full_size_schedules and not full_baseline and not cfg5 and not at_size'
 for e in "TRT_RAY_POOL=0" "TRT_FLAT_WALK=0" "TRT_LDS_LEAF_STACK=0" "TRT_COMPACT_NODES=0" "TRT_STREAM_MINW=5" "TRT_STREAM_MINW=7" "TRT_STREAM_MINW=8" "TRT_LEAF_SLOTS=1" "TRT_LEAF_SLOTS=2" \
-         "TRT_ORDERED_WALK=1" "TRT_RUNTIME_WALK=1" "TRT_BIG_THREADS=512" "TRT_STRAGGLERS=0" "TRT_STRAGGLERS=40"; do
-  echo "== $e: $(env $e timeout -k 10 300 python -m pytest tests -x -q -m gpu -k 'not leaf_slots_are and not lockstep and not global_memory_walks and not full_size_schedules and not full_baseline and not cfg5' 2>&1 | tail -1)"
+         "TRT_RUNTIME_WALK=1" "TRT_BIG_THREADS=512" "TRT_STRAGGLERS=0" "TRT_STRAGGLERS=40" $TRT_EXTRA_KNOBS; do
+  log=$out/$e.log
+  env $e AMD_LOG_LEVEL=1 PYTHONFAULTHANDLER=1 timeout -k 10 300 python3 -X faulthandler -m pytest tests -x -q -m gpu -k "$skip" > "$log" 2>&1
+  rc=$?
+  echo "== $e: rc=$rc $(tail -1 "$log")"
+  if [ $rc -ne 0 ]; then
+    echo "---- last 60 lines of $log ----"; tail -60 "$log"
+    exit $rc
+  fi
 done
