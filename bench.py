@@ -190,7 +190,7 @@ def main():
 
     W, H = args.width, args.height
     desc = {"cornell": trt.scenes.cornell, "random_spheres": trt.scenes.random_spheres,
-            "sphere_grid": lambda w, h: trt.scenes.sphere_grid(100000, w, h)}[args.scene](W, H)
+            "sphere_grid": lambda w, h: trt.scenes.sphere_grid(int(os.environ.get("TRT_BENCH_SPHERES", "100000")), w, h)}[args.scene](W, H)
     world, cam = trt.world_from_description(desc)
     scene = world.get_bvh()
     total_spp = FRAME_SPP

@@ -184,6 +184,14 @@ impl World {
         Ok(self.scene)
     }
 
+    /// Frees the device scratch (render workspaces, frame buffers) the compiled scene caches between renders.
+    pub fn trim(&mut self) -> Result<(), Error> {
+        if self.scene.is_null() {
+            return Ok(());
+        }
+        check(unsafe { sys::trt_scene_trim(self.scene) })
+    }
+
     fn invalidate(&mut self) {
         if !self.scene.is_null() {
             unsafe { sys::trt_scene_destroy(self.scene) };

@@ -93,6 +93,8 @@ public:
         return scene_;
     }
     int num_geometries() const { return trt_world_num_geometries(w_); }
+    // Frees the device scratch (render workspaces, frame buffers) the compiled scene caches between renders (trt_scene_trim).
+    void trim() { if (scene_) check(trt_scene_trim(scene_)); }
 
 private:
     void invalidate() { if (scene_) { trt_scene_destroy(scene_); scene_ = nullptr; } }
