@@ -231,3 +231,30 @@ def test_powf_v1_is_the_correctly_rounded_power_almost_everywhere(orc):
     finally:
         orc.lib.orc_set_use_libm(0)
     assert np.abs(libm.view(np.int32).astype(np.int64) - got[:5000].view(np.int32).astype(np.int64)).max() <= 1
+
+
+def test_u8_frame_of_trt_powf_against_platform_libm_powf(orc, trt):
+    """host tonemap, device tonemap and oracle share ONE powf (trt-math v1), so their byte-exact agreement compares the
+    algorithm with itself; the reference calls the platform's libm powf (utils/image.rs:94-96).  Here the quantised frame of the
+    product's tonemap is compared with the oracle's in LIBM mode (glibc powf) on a rendered frame and on 2 M synthetic channel
+    values: a channel may differ by one least-significant bit (where the two powf round differently right at a quantisation step)
+    and does so for fewer than one value in 10^4 - a regression of either implementation shows up as a larger step or rate."""
+    desc = trt.scenes.cornell(96, 96)
+    ow, ocam = orc.world_from_description(desc)
+    frame, _ = orc.render(ow, ocam, 16, 12, desc["background"], seed=3, nthreads=4)
+    rng = np.random.default_rng(11)
+    synth = np.concatenate([rng.random(1_000_000), np.exp(rng.uniform(-12, 3, 1_000_000))]).astype(np.float32)
+    synth = np.resize(synth, (len(synth) // 3) * 3)
+    for values in (frame.reshape(-1), synth):
+        img = trt.Image(values.reshape(-1, 1, 3).copy())
+        mine = img.to_u8().reshape(-1).astype(np.int32)                 # libtinyrt's host tonemap (trt-math v1 powf), no GPU needed
+        orc.lib.orc_set_use_libm(1)
+        try:
+            libm = orc.tonemap_u8(values.reshape(-1, 3)).reshape(-1).astype(np.int32)
+        finally:
+            orc.lib.orc_set_use_libm(0)
+        own = orc.tonemap_u8(values.reshape(-1, 3)).reshape(-1).astype(np.int32)
+        assert np.array_equal(mine, own)                                # same function on both sides: equal
+        diff = np.abs(mine - libm)
+        assert diff.max() <= 1, int(diff.max())
+        assert (diff != 0).mean() < 1e-4, float((diff != 0).mean())
