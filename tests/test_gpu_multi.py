@@ -207,3 +207,60 @@ def test_multi_gpu_c_example_renders_identical_frames(tmp_path):
     r = subprocess.run([exe, "512", "500", "16"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
 
+
+
+def test_mixed_entry_points_from_eight_threads_on_two_scenes(trt):
+    """Every blocking entry point at once, on two scene handles: trt_render (streamed, wavefront, megakernel; several image sizes, so
+    workspaces and context frames are regrown while others are in flight), trt_render_multi with three and five shards, and
+    trt_sample_batch - eight host threads, four repetitions, with the idle-scratch cap forcing trims in between.  Every result equals
+    the one computed alone.  (The round-3 host layer under its real runtime; its logic alone runs under TSan / ASan on the simulated
+    runtime in tests/test_host_sanitizers.py.)"""
+    import ctypes as C
+    cornell = {sz: trt.scenes.cornell(*sz) for sz in ((192, 160), (320, 200), (96, 96))}
+    spheres = trt.scenes.random_spheres(240, 135)
+    wc, _ = trt.world_from_description(cornell[(192, 160)])
+    cams = {sz: trt.world_from_description(d)[1] for sz, d in cornell.items()}
+    ws, cam_s = trt.world_from_description(spheres)
+    scene_c, scene_s = wc.get_bvh(), ws.get_bvh()
+    bg_c, bg_s = cornell[(192, 160)]["background"], spheres["background"]
+
+    def batch_points(n):
+        pts = (trt.SamplePoint * n)()
+        for i in range(n):
+            pts[i].x, pts[i].y = i % 16, i // 16
+            pts[i].ray.origin = trt.Vec3(50.0, 50.0, -140.0)
+            pts[i].ray.direction = trt.Vec3(0.01 * (i % 16) - 0.08, 0.01 * (i // 16) - 0.08, 1.0)
+        return pts
+
+    jobs = []
+    for k, (sz, be) in enumerate((((192, 160), trt.BACKEND_STREAMED), ((320, 200), trt.BACKEND_WAVEFRONT), ((96, 96), trt.BACKEND_MEGAKERNEL),
+                                  ((320, 200), trt.BACKEND_STREAMED))):
+        jobs.append(("render", lambda sz=sz, be=be, k=k: trt.Renderer(6, 1, 10, False, bg_c, seed=20 + k, backend=be).render(cams[sz], scene_c).data))
+    jobs.append(("multi3", lambda: trt.Renderer(5, 1, 10, False, bg_c, seed=31).render_multi(cams[(320, 200)], scene_c, devices=[0, 0, 0]).data))
+    jobs.append(("multi5", lambda: trt.Renderer(4, 1, 12, False, bg_s, seed=32).render_multi(cam_s, scene_s, devices=[0] * 5).data))
+    jobs.append(("spheres", lambda: trt.Renderer(8, 1, 12, False, bg_s, seed=33).render(cam_s, scene_s).data))
+
+    def batch():
+        out, _ = trt.sample_batch(scene_c, batch_points(256), 8, bg_c, seed=5, collect_stats=False)
+        return np.array([[c.color.x, c.color.y, c.color.z] for c in out], np.float32)
+    jobs.append(("batch", batch))
+    serial = [fn() for _, fn in jobs]
+    for rep in range(4):
+        got, errors = [None] * len(jobs), []
+
+        def work(i):
+            try:
+                got[i] = jobs[i][1]()
+            except Exception as ex:                                      # noqa: BLE001 - reported below
+                errors.append((jobs[i][0], ex))
+
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for i, (name, _) in enumerate(jobs):
+            assert np.array_equal(bits(got[i]), bits(serial[i])), (rep, name)
+        if rep == 1:
+            trt._lib.check(trt.lib.trt_scene_trim(scene_c._h))            # frees every idle cached buffer; the next repetition re-grows them

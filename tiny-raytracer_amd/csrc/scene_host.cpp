@@ -157,7 +157,8 @@ uint16_t f32_to_f16_dir(float x, bool up) {
 }
 
 struct CullBuilder {
-    double kPrune = 0.7;                     // measured best on MI355X (0.5-0.9 within 3 %); env TRT_CULL_PRUNE overrides (tuning; any value gives the same hits)
+    double kPrune = 0.5;                     // measured best on MI355X (round 3, profiles/r03_defaults_sweep.txt: random-spheres 0.4-0.5 beat 0.7 by 3 %, the
+                                             // 100 k-sphere scene is flat from 0.3 to 0.7); env TRT_CULL_PRUNE overrides (tuning; any value gives the same hits)
     const std::vector<Box>& leaf_box;        // leaf k of the reference tree, in left-first order
     std::vector<Box> node_box;
     std::vector<int32_t> node_leaf;          // leaf sequence number or -1

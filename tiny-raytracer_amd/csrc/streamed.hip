@@ -406,10 +406,11 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     if (threads == 768) w = 6;
     if (mode == MODE_HYBRID) w = 1;                                               // one instantiation only (tuning knob TRT_TOP_NODES)
     uint32_t wg_per_cu = mode == MODE_HYBRID ? 4u : (uint32_t)(w * 4 * 64 / threads);
-    // slots of the LDS stack: 4 for tree walks; 7 for the lock-step leaf list, whose t_best stays stale for a whole walk
-    // (Cornell 34.0 Gray/s at 4, 35.1 at 6..12) and which steps two leaves per trip, so a lane must have two free
+    // slots of the LDS stack: 4 for tree walks (5 in the 768-lane plan if they fit: random-spheres +3 %, profiles/r03_defaults_sweep.txt);
+    // 7 for the lock-step leaf list, whose t_best stays stale for a whole walk (Cornell 34.0 Gray/s at 4, 35.1 at 6..12) and which
+    // steps two leaves per trip, so a lane must have two free
     const bool flat = L.flat_walk && !ra_all.ref_tree;
-    uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 7u : 4u) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
+    uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 7u : (threads == 768 ? 5u : 4u)) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
     if (flat && slots < 2u) slots = 2u;                                         // walk_flat pushes up to two leaves per trip
     if (flat && ra_all.leaf_slots == 0u && mode == MODE_LDS && threads == 256) {
         // the default depth gives way to occupancy: the deepest stack (<= 7, >= 4) with which stack + ray pool + scene copy of

@@ -111,6 +111,44 @@ int main(int argc, char** argv) {
           for (int k = 0; k < nsec; k++) walk(&tmp[k].r, &T2[k]);
           for (int w0 = 0; w0 < nsec; w0 += 64) { int n = nsec - w0 < 64 ? nsec - w0 : 64; for (int l = 0; l < n; l++) tp[l] = &T2[w0 + l]; wave_lines(tp, n, &loc, &coc, &noc); } }
     }
+    // (5) a GLOBAL sort: the first-bounce rays of a whole (coarse) frame sorted by origin cell (2 x 2 world units) and direction octant,
+    //     cut into waves of 64 - what a wavefront design with ray queues in HBM would feed the walk
+    {
+        int gw = W / 8, gh = H / 8, cap = gw * gh, ng = 0;                        // one primary ray per 8x8 pixels
+        Sec* all = malloc(sizeof(Sec) * (size_t)cap);
+        Trace* t1 = malloc(sizeof(Trace));
+        for (int gy = 0; gy < gh; gy++) for (int gx = 0; gx < gw; gx++) {
+            Ray r; float u = ((float)(gx * 8) + urand() * 8) / (float)(W - 1), v = ((float)(gy * 8) + urand() * 8) / (float)(H - 1), dir[3], len = 0;
+            for (int a = 0; a < 3; a++) { r.o[a] = cam[a]; dir[a] = cam[3 + a] + u * cam[6 + a] - v * cam[9 + a] - cam[a]; len += dir[a] * dir[a]; }
+            len = sqrtf(len); for (int a = 0; a < 3; a++) r.d[a] = dir[a] / len;
+            walk(&r, t1);
+            if (t1->prim < 0) continue;
+            float p[3], n[3], nl = 0;
+            for (int a = 0; a < 3; a++) { p[a] = r.o[a] + t1->t * r.d[a]; n[a] = p[a] - sph[t1->prim][a]; nl += n[a] * n[a]; }
+            nl = sqrtf(nl);
+            float z = 1 - 2 * urand(), ph = 6.2831853f * urand(), s = sqrtf(fmaxf(0.f, 1 - z * z)), rv[3] = {s * cosf(ph), s * sinf(ph), z}, dl = 0;
+            Sec* q = &all[ng];
+            for (int a = 0; a < 3; a++) { q->r.o[a] = p[a]; dir[a] = n[a] / nl + rv[a]; dl += dir[a] * dir[a]; }
+            dl = sqrtf(dl); if (dl < 1e-6f) continue;
+            for (int a = 0; a < 3; a++) q->r.d[a] = dir[a] / dl;
+            int oct = (q->r.d[0] < 0) | (q->r.d[1] < 0) << 1 | (q->r.d[2] < 0) << 2;
+            int cx = ((int)floorf(q->r.o[0] * 0.5f) + 512) & 1023, cz = ((int)floorf(q->r.o[2] * 0.5f) + 512) & 1023;
+            q->key = (cx * 1024 + cz) * 8 + oct;
+            ng++;
+        }
+        double lu = 0, nu = 0, lso = 0, nso = 0; long cu = 0, cso = 0;
+        Trace* TT = malloc(sizeof(Trace) * 64);
+        for (int pass = 0; pass < 2; pass++) {
+            if (pass == 1) qsort(all, (size_t)ng, sizeof(Sec), cmp_sec);
+            for (int w0 = 0; w0 + 64 <= ng; w0 += 64 * 7) {                       // every 7th wave is enough for the average
+                for (int l = 0; l < 64; l++) { walk(&all[w0 + l].r, &TT[l]); tp[l] = &TT[l]; }
+                if (pass == 0) wave_lines(tp, 64, &lu, &cu, &nu); else wave_lines(tp, 64, &lso, &cso, &nso);
+            }
+        }
+        printf("first-bounce rays of the whole frame (%d rays), 64 per wave:\n", ng);
+        printf("  in image order (8x8-pixel spacing):                   %.1f lines  (%.1f lanes, %ld loads)\n", lu / cu, nu / cu, cu);
+        printf("  globally sorted by origin cell and octant:            %.1f lines  (%.1f lanes, %ld loads)\n", lso / cso, nso / cso, cso);
+    }
     printf("distinct 128-byte lines per wave load (and live lanes per load), lock-step model of the binary 16-byte-node walk:\n");
     printf("  primary rays of an 8x8 tile:                         %.1f lines  (%.1f lanes, %ld loads)\n", lp / cp, np_ / cp, cp);
     printf("  secondary rays, lanes as they fall (what runs now):   %.1f lines  (%.1f lanes, %ld loads)\n", ls / cs, ns_ / cs, cs);
