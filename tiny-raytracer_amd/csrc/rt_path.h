@@ -548,12 +548,18 @@ TRT_DEV bool shade_hit(const SceneAcc<MODE>& sc, Path& p, uint32_t prim, float t
         p.color = p.color + p.atten * emission;
     }
     V3 dir;
-    if (kind == TRT_LAMBERTIAN) {                                      // lambertian.rs:16-22
-        dir = normal + random_unit_vector(p.rng);
-        if (near_zero(dir)) dir = normal;
-    } else if (kind == TRT_METAL) {                                    // metal.rs:18-25 (fuzz clamped at creation)
-        V3 reflected = reflect(p.ray.d, normal);
-        dir = reflected + m.w * random_in_unit_sphere(p.rng);
+    if (kind == TRT_LAMBERTIAN || kind == TRT_METAL) {
+        // Both draw ONE point in the unit sphere (three random numbers, acos, cbrt, two sincos: the expensive part of a shade) and use
+        // it differently: evaluated once for the lanes of either kind - as two branches a wave that holds both kinds (nearly every wave
+        // of the random-spheres scene) ran that code twice, the second time for a handful of metal lanes.  Same draws, same operations.
+        const V3 in_sphere = random_in_unit_sphere(p.rng);
+        if (kind == TRT_LAMBERTIAN) {                                  // lambertian.rs:16-22: normal + random_unit_vector (vec3extend.rs:32-34)
+            dir = normal + normalized(in_sphere);
+            if (near_zero(dir)) dir = normal;
+        } else {                                                       // metal.rs:18-25 (fuzz clamped at creation)
+            V3 reflected = reflect(p.ray.d, normal);
+            dir = reflected + m.w * in_sphere;
+        }
     } else if (kind == TRT_DIELECTRIC) {                               // dielectric.rs:26-46
         float ri = front_face ? 1.0f / m.w : m.w;
         float cosv = __builtin_fminf(-dot(normal, p.ray.d), 1.0f);
