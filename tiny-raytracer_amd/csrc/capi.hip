@@ -427,7 +427,7 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     ra.lds_leaf_stack = 1u;
     if (const char* e = getenv("TRT_LDS_LEAF_STACK")) ra.lds_leaf_stack = (uint32_t)atoi(e);   // 0 off, 1 where it costs no occupancy, 2 always
     ra.xcd_aware = getenv("TRT_XCD_REMAP") ? 1u : 0u;   // off: contiguous image regions per XCD measured 2x slower (load imbalance)
-    ra.stragglers = 12u;                                   // scheduling only: any value renders the same frame
+    ra.stragglers = 8u;                                    // scheduling only: any value renders the same frame (profiles/r03_stragglers_sweep.txt)
     if (const char* e = getenv("TRT_STRAGGLERS")) ra.stragglers = (uint32_t)atoi(e);
     ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;

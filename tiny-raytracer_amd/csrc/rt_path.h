@@ -289,16 +289,40 @@ TRT_DEV void leaf_phase(const float2* stk, const float2* top, Trav& tr, Counters
     }
 }
 
+// A walk that is left unfinished (resumable walks below) parks its cursor, its t_best and its best primitive in the lane's leaf stack,
+// which is empty at that moment; the caller sets the walk up again from the ray (trav_begin: the three 1/d are recomputed, in the same
+// instruction stream in which the wave's other lanes start their new walks) and takes the three values back.  Nothing of the walk is then
+// live in registers while the finished lanes are shaded: kept in VGPRs, those 9 registers cost the random-spheres kernel 12 %.
+TRT_DEV void trav_park(float2* stk, const Trav& tr) {
+    stk[0] = make_float2(__uint_as_float(tr.i), tr.t_best);
+    stk[64] = make_float2(__uint_as_float(tr.prim_best), 0.0f);
+}
+TRT_DEV void trav_unpark(const float2* stk, Trav& tr) {
+    const float2 a = stk[0], b = stk[64];
+    tr.i = __float_as_uint(a.x);
+    tr.t_best = a.y;
+    tr.prim_best = __float_as_uint(b.x);
+}
+
 // The same walk with the postponed leaves in LDS instead of registers: `stk` is this lane's slot 0, slot k lives at
 // stk[64 * k] (one 8-byte (leaf, start) pair per lane and slot, lane-contiguous: conflict-free ds_write_b64 /
 // ds_read_b64).  Putting a leaf aside costs one address, one LDS write and one add instead of the compare/select
 // chain over SLOTS registers (13 VALU instructions per box-step trip at 4 slots: the wave pays them whenever ANY lane
 // finds a leaf, which is nearly every trip), and the slots cost no VGPRs.  LDS operations of one wave complete in
 // order, so a lane reads back what it wrote without a barrier.
+// Resumable (round 3), like walk_compact: with `stragglers` > 0 the function returns false - walk unfinished, tr holds where it stands, the
+// leaf stack is empty - as soon as at most that many lanes of the wave still walk while others have finished.  The walk lengths of a wave's
+// 64 rays are spread widely (random-spheres: mean 26 box steps, 95th percentile 47, longest of 64 about 55), and a round runs as many trips
+// as its longest walk: carrying the few long ones into the next round cuts the trips per ray by a third in the model
+// (tools/proto/cull_tree_model.c + the walk-length replay in profiles/r03_stragglers_model.txt).
 template <int MODE, bool STATS>
-TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots) {
+TRT_DEV bool walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots,
+                           uint32_t stragglers = 0u, uint32_t entered = 64u) {
     const uint32_t n = sc.L.n_cull_nodes;
     float2* const limit = stk + 64u * slots;
+    // the walk is left once at most `few` lanes still walk: no more than `stragglers`, and fewer than came in (so that a round always
+    // finishes some walk); 0 = never (at least one lane is active wherever it is compared)
+    const uint32_t few = stragglers < entered ? stragglers : entered - 1u;
     for (;;) {
         float2* top = stk;
         while (tr.i < n && top != limit) {
@@ -314,11 +338,17 @@ TRT_DEV void walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
                 *top = make_float2(nb.w, start);
                 top += 64;
             }
+            // resumable: once only a few lanes are still stepping boxes (the others finished, or wait with a full leaf stack), stop
+            // stepping: the pending leaves are tested and the check below decides whether the walk is left (s_bcnt1 of the exec mask
+            // and one scalar compare per trip)
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= few) break;
         }
         TRT_CLK(ctr, 1);
-        if (top == stk) break;
-        leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
+        if (top == stk && tr.i >= n) return true;
+        if (top != stk) leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
         TRT_CLK(ctr, 2);
+        if (tr.i >= n) return true;
+        if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= few) { trav_park(stk, tr); return false; }
     }
 }
 
@@ -397,6 +427,7 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
                           uint32_t entered = 64u) {
     const uint32_t n = sc.L.n_cull_nodes;
     float2* const limit = stk + 64u * slots;
+    const uint32_t few = stragglers < entered ? stragglers : entered - 1u;             // see walk_fast_lds
     for (;;) {
         float2* top = stk;
         // (Measured and rejected in round 2: requesting nodes i and i + 1 together and stepping i + 1 from the data already
@@ -417,23 +448,21 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
                 top += 64;
             }
             tr.i = (pass || is_leaf) ? next : q.w;
+            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= few) break;      // see walk_fast_lds
         }
         TRT_CLK(ctr, 1);
-        if (top == stk) return true;
+        if (top == stk && tr.i >= n) return true;
         // The coarse box contains the exact one, so its interval starts no later: a leaf whose COARSE start is not below the
         // current t_best fails the exact test too and is dropped by the scan without touching memory; the others take the
         // reference's leaf-box test on the exact f32 box, at the leaf's turn.
-        leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) {
+        if (top != stk) leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) {
             const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
             if constexpr (STATS) ctr.node++;
             if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
         });
         TRT_CLK(ctr, 2);
         if (tr.i >= n) return true;
-        if (stragglers != 0u) {                                                          // resumable: see walk_fast_lds
-            const uint32_t walking = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-            if (walking <= stragglers && walking < entered) return false;
-        }
+        if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= few) { trav_park(stk, tr); return false; }      // resumable: see walk_fast_lds
     }
 }
 
@@ -477,13 +506,17 @@ TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_
     return tr.prim_best;
 }
 
-// The 16-byte-node walk in resumable form (WALK_COMPACT): `tr` is set up by the caller (trav_begin) when the ray
-// starts its walk and kept while the function returns false.  Returns true when the walk is complete (tr.t_best / tr.prim_best).
+// The per-lane tree walks in resumable form (WALK_COMPACT: 16-byte nodes from global memory; WALK_LDS_STACK: the culling tree in LDS): `tr`
+// is set up by the caller (trav_begin) when the ray starts its walk and kept while the function returns false.  Returns true when the
+// walk is complete (tr.t_best / tr.prim_best).
 template <int MODE, bool STATS, int WALK>
 TRT_DEV bool closest_hit_resume(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr, uint32_t leaf_slots, float2* lds_stack,
                                 const float4* __restrict__ leaf_list, const uint4* __restrict__ nodes16, uint32_t stragglers, uint32_t entered) {
-    static_assert(WALK == WALK_COMPACT, "only the 16-byte-node walk can be left and resumed");
-    if (__builtin_expect(!tr.ref, 1)) return walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots, stragglers, entered);
+    static_assert(WALK == WALK_COMPACT || WALK == WALK_LDS_STACK, "only the per-lane tree walks with an LDS leaf stack can be left and resumed");
+    if (__builtin_expect(!tr.ref, 1)) {
+        if constexpr (WALK == WALK_COMPACT) return walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots, stragglers, entered);
+        else return walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots, stragglers, entered);
+    }
     closest_hit_ref<MODE, STATS>(sc, ray, tr, ctr);
     return true;
 }

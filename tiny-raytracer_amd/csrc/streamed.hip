@@ -28,6 +28,7 @@
 namespace trt {
 
 constexpr uint32_t kBatchSpp = 8;            // samples per pixel in one batch
+constexpr uint32_t kLdsStragglers = 8;       // LDS tree walk: lanes that may carry an unfinished walk into the next round (TRT_LDS_STRAGGLERS; 0 = none)
 
 TRT_DEV uint32_t st_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -64,11 +65,10 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     Rng stock_rng;
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
-    // resumable walks (rt_path.h walk_compact) pay for scenes walked from global memory (100 k spheres: 324 trips per round for 222
-    // box steps per ray; +10 %); for LDS-resident trees the carried walk state and the extra rounds cancel the gain (random-spheres +-0)
-    constexpr bool kResumable = !STATS && WALK == WALK_COMPACT;
-    Trav tr{};                                                                    // a walk under way (kResumable only)
-    bool walking = false;
+    // resumable walks (rt_path.h walk_compact, walk_fast_lds): a round's walk phase ends once only a few lanes still walk; they carry
+    // their walk into the next round (100 k spheres: 324 trips per round for 222 box steps per ray, +10 %; random-spheres: see DESIGN 13)
+    constexpr bool kResumable = !STATS && (WALK == WALK_COMPACT || WALK == WALK_LDS_STACK);
+    bool walking = false;                                                         // this lane's walk is parked in its leaf stack (kResumable only)
 
     TRT_CLK_START(ctr);
     for (;;) {
@@ -128,10 +128,11 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (kResumable) {
                 // per-lane tree walk: a lane whose walk is still under way when most of the wave has finished carries it into the
                 // next round (rt_path.h walk_compact) and is not shaded in this one
-                if (!walking) { tr = trav_begin(sc, p.ray, false); walking = true; n_rays++; }
+                Trav tr = trav_begin(sc, p.ray, false);                              // every lane: a new walk, or the frame of a parked one
+                if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-                if (closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered)) {
-                    walking = false;
+                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
+                if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
                         float* c = colors + 3ull * out_idx;
                         c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -196,11 +197,10 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
     uint32_t out_idx = 0;
     uint32_t n_samples = 0, n_rays = 0;
     Counters<STATS> ctr;
-    // resumable walks (rt_path.h walk_compact) pay for scenes walked from global memory (100 k spheres: 324 trips per round for 222
-    // box steps per ray; +10 %); for LDS-resident trees the carried walk state and the extra rounds cancel the gain (random-spheres +-0)
-    constexpr bool kResumable = !STATS && WALK == WALK_COMPACT;
-    Trav tr{};                                                                    // a walk under way (kResumable only)
-    bool walking = false;
+    // resumable walks (rt_path.h walk_compact, walk_fast_lds): a round's walk phase ends once only a few lanes still walk; they carry
+    // their walk into the next round (100 k spheres: 324 trips per round for 222 box steps per ray, +10 %; random-spheres: see DESIGN 13)
+    constexpr bool kResumable = !STATS && (WALK == WALK_COMPACT || WALK == WALK_LDS_STACK);
+    bool walking = false;                                                         // this lane's walk is parked in its leaf stack (kResumable only)
 
     TRT_CLK_START(ctr);
     for (;;) {
@@ -267,10 +267,11 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
         if (has_path) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             if constexpr (kResumable) {
-                if (!walking) { tr = trav_begin(sc, p.ray, false); walking = true; n_rays++; }     // see stream_sample_kernel
+                Trav tr = trav_begin(sc, p.ray, false);                              // see stream_sample_kernel
+                if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-                if (closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered)) {
-                    walking = false;
+                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
+                if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
                         float* c = colors + 3ull * out_idx;
                         c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
@@ -515,6 +516,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     CameraDev camd = cam;
     const float4* leaf_list = (pl.flat || pl.compact) ? sc.blob + sc.L.off_leaf_list : nullptr;
     const uint4* nodes16 = pl.compact ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_compact) : nullptr;
+    const int walk_of_plan = pl.walk;
     const uint32_t resident = (uint32_t)cus * pl.wg_per_cu;
     const uint32_t waves_per_wg = (uint32_t)pl.threads / 64u;
     if (pl.lds_bytes > 48u * 1024u) {
@@ -526,6 +528,11 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         RenderArgs ra = ra_all;
         ra.lds_leaf_stack = pl.lds_stack ? 1u : 0u;
         if (pl.lds_stack) ra.leaf_slots = pl.slots;
+        if (walk_of_plan == WALK_LDS_STACK) {                                   // the LDS tree walk's own straggler threshold
+            ra.stragglers = kLdsStragglers;
+            if (const char* env = getenv("TRT_LDS_STRAGGLERS")) ra.stragglers = (uint32_t)atoi(env);
+        }
+        if (!pl.lds_stack || pl.slots < 2u) ra.stragglers = 0u;                 // a parked walk occupies two slots of the lane's LDS leaf stack (rt_path.h trav_park)
         ra.sample_begin = s0;
         ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;
         uint32_t batch_spp = kBatchSpp;

@@ -86,6 +86,7 @@ int main(int argc, char** argv) {
                 for (int l = 0; l < 64; l++) if (live[l]) {
                     float t; int prim; int s = walk(&path[l], slots, &t, &prim);
                     steps += s; rays++; nl++; if (s > mx) mx = s;
+                    if (getenv("DUMP_STEPS")) { static FILE* df; if (!df) df = fopen(getenv("DUMP_STEPS"), "w"); fprintf(df, "%d %d\n", bounce, s); }
                     if (prim < 0) { live[l] = 0; continue; }
                     float p[3], n[3], nlen = 0, dir[3], dl = 0;
                     for (int a2 = 0; a2 < 3; a2++) { p[a2] = path[l].o[a2] + t * path[l].d[a2]; n[a2] = p[a2] - sph[prim][a2]; nlen += n[a2] * n[a2]; }
