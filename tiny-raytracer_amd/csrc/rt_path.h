@@ -367,18 +367,17 @@ template <int MODE, bool STATS>
 TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf_list, const Ray& ray, Trav& tr, Counters<STATS>& ctr,
                        float2* stk, uint32_t slots) {
     const uint32_t n = sc.L.n_leaves;                    // >= 1
-    const uint32_t last = n - 1u;
     uint32_t i = 0;                                      // wave-uniform
-    float4 a0 = leaf_list[0], b0 = leaf_list[1];
-    const uint32_t i1 = last < 1u ? last : 1u;
-    float4 a1 = leaf_list[2u * i1], b1 = leaf_list[2u * i1 + 1u];
+    const float4* __restrict__ pair = leaf_list;         // wave-uniform: the pair under test; the list is padded (scene.h kLeafListPad), so
+                                                         // reading one pair ahead needs no clamping: ONE 64-byte scalar load per trip
+    float4 a0 = pair[0], b0 = pair[1], a1 = pair[2], b1 = pair[3];
     float2* const limit = stk + 64u * (slots - 2u);      // a lane whose top is beyond it cannot hold another pair (slots >= 2)
     do {
         float2* top = stk;
         for (; i < n;) {
-            // request the next pair (indices clamped to the list: a harmless re-read at the end)
-            const uint32_t j0 = i + 2u < last ? i + 2u : last, j1 = i + 3u < last ? i + 3u : last;
-            const float4 na0 = leaf_list[2u * j0], nb0 = leaf_list[2u * j0 + 1u], na1 = leaf_list[2u * j1], nb1 = leaf_list[2u * j1 + 1u];
+            // request the next pair
+            pair += 4;
+            const float4 na0 = pair[0], nb0 = pair[1], na1 = pair[2], nb1 = pair[3];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
             float start;
             if (slab_fast_entry(a0, b0, ray.o, tr.inv, kTMin, tr.t_best, start)) {

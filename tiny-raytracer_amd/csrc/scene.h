@@ -67,7 +67,7 @@ struct World {
 //   [material: nm] (albedo.rgb, param)
 //   [sphere_material: ns] u32   [material_kind: nm] u32          (padded to 16 bytes)   <- hot_bytes end here
 //   [reference nodes: 2n] same node format
-//   [leaf list: 2 per leaf] the leaves of the trees in walk order, same node format (skip = successor)
+//   [leaf list: 2 per leaf (+ kLeafListPad copies of the last)] the leaves of the trees in walk order, same node format (skip = successor)
 //   [compact culling tree: 1 per node] scenes too large for LDS only: (f16 lo.xy | lo.z,hi.x | hi.yz | skip or LEAF|k),
 //       boxes rounded OUTWARD to f16, pre-order (an inner node's first child is the next node)
 struct SceneLayout {
@@ -89,6 +89,7 @@ struct SceneLayout {
 };
 // Largest hot blob (SceneLayout::hot_bytes) copied whole into LDS, once per workgroup; larger scenes are read from global memory.
 constexpr uint32_t kLdsSceneMaxBytes = 64u * 1024u;
+constexpr uint32_t kLeafListPad = 4;          // copies of the last leaf behind the leaf list (walk_flat reads ahead without clamping)
 constexpr uint32_t kFlatWalkMaxLeaves = 32;   // at most this many primitives: lock-step leaf list instead of the culling tree
 
 struct NodeDump {                            // pre-order inspection copy of one tree

@@ -306,7 +306,7 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     L.off_ref_nodes = L.hot_bytes / 16u;
     L.n_leaves = (uint32_t)leaf_box.size();
     L.off_leaf_list = L.off_ref_nodes + 2u * nn;
-    L.blob_bytes = L.hot_bytes + 32u * nn + 32u * L.n_leaves;
+    L.blob_bytes = L.hot_bytes + 32u * nn + 32u * (L.n_leaves + kLeafListPad);     // the leaf list is followed by kLeafListPad copies of its last entry
     L.off_compact = 0u;
     bool want_compact = L.hot_bytes > kLdsSceneMaxBytes;                      // scenes walked from global memory
     if (const char* e = getenv("TRT_COMPACT_NODES")) want_compact = atoi(e) != 0;             // tuning / tests; same frames either way
@@ -317,7 +317,7 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     {   // every offset and size of the layout is 32 bits wide: refuse scenes that do not fit instead of wrapping around
         const uint64_t prims = (uint64_t)ns + 5ull * nq + nm;
         const uint64_t total = 16ull * (2ull * nc + prims) + 4ull * ((uint64_t)ns + nm) + 16ull                 // hot part
-                               + 32ull * nn + 32ull * L.n_leaves                                                  // reference tree, leaf list
+                               + 32ull * nn + 32ull * ((uint64_t)L.n_leaves + kLeafListPad)                          // reference tree, leaf list
                                + (want_compact ? 16ull * nc : 0ull);
         if (total > 0xFFFFFFFFull) { msg = "scene too large: the packed scene would exceed 4 GiB"; return false; }
     }
@@ -392,6 +392,13 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
         std::vector<uint32_t> lplace(nl);
         for (uint32_t k = 0; k < nl; k++) { lskip[k] = (int32_t)k + 1; lplace[k] = k; }
         pack_nodes(f4 + L.off_leaf_list, leaf_box, lprim, lskip, lplace);
+        // padding: the lock-step walk requests the NEXT pair of leaves before it tests the current one, without clamping the index
+        // (rt_path.h walk_flat); what it reads beyond the list are copies of the last leaf, which it never tests
+        for (uint32_t k = 0; k < kLeafListPad; k++) {
+            F4* last = f4 + L.off_leaf_list + 2u * (size_t)(nl - 1u);
+            F4* dst = f4 + L.off_leaf_list + 2u * (size_t)(nl + k);
+            dst[0] = last[0]; dst[1] = last[1];
+        }
     }
     if (L.off_compact) {   // compact culling tree: f16 boxes rounded outward (any superset box keeps the hits: DESIGN.md 4.1), pre-order
         uint32_t* c = u32 + 4u * (size_t)L.off_compact;
