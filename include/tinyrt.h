@@ -218,7 +218,7 @@ int trt_sample_batch(trt_scene *s, const trt_sample_point *in, uint32_t n, trt_s
 int trt_tonemap_u8(const float *accum, uint32_t npixels, float gamma, uint8_t *rgb);
 
 /* The same on buffers resident in HBM (device pointers), asynchronous on `stream` (a hipStream_t, NULL = default): the
- * frame never has to leave the GPU as f32.  Host form and device kernel evaluate c^(1/gamma) with the same function (trt-math v1
+ * frame never has to leave the GPU as f32.  Host form and device kernel evaluate c^(1/gamma) with the same function (trt-math v2
  * powf, csrc/trt_pow.h): their u8 frames are equal byte for byte.  Against the reference, which calls the platform's libm powf
  * (utils/image.rs:94-96), a channel may differ by one least-significant bit where that powf is not correctly rounded. */
 int trt_tonemap_u8_device(const float *d_accum, uint32_t npixels, float gamma, uint8_t *d_rgb, void *stream);

@@ -69,9 +69,12 @@ static int v3_eq(vec3 a, vec3 b) {
 }
 
 /* ------------------------------------------------------------------------------------------
- * trt-math v1: fixed f32 algorithms standing in for the platform libm the Rust std calls
- * (acos/cbrt/sin/cos at vec3extend.rs:21-27).  Only + - * / sqrt, compares and bit moves,
- * each correctly rounded on x86-64 SSE and on gfx950, so both sides agree bit for bit.
+ * trt-math v2: fixed f32 algorithms standing in for the platform libm the Rust std calls
+ * (acos/cbrt/sin/cos at vec3extend.rs:21-27).  Only + - * sqrt, fused multiply-add (fmaf),
+ * compares and bit moves, each correctly rounded on x86-64 (SSE + FMA3) and on gfx950, so both
+ * sides agree bit for bit.  v2 differs from v1 (rounds 1-3) in evaluating every polynomial as an
+ * fma Horner chain and in a cube root without divisions; the polynomials and the argument
+ * reductions are v1's.  The build passes -ffp-contract=off: only the fmaf() written here fuses.
  * ---------------------------------------------------------------------------------------- */
 static int g_use_libm = 0;
 void orc_set_use_libm(int on) { g_use_libm = on; }
@@ -89,11 +92,11 @@ static void m_sincos(float x, float *sn, float *cs) {
     uint32_t j = (uint32_t)(ax * FOPI);
     j = (j + 1u) & ~1u;
     float y = (float)j;
-    float r = ((ax - y * DP1) - y * DP2) - y * DP3;
+    float r = fmaf(-y, DP3, fmaf(-y, DP2, fmaf(-y, DP1, ax)));
     float z = r * r;
-    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z + -1.6666654611e-1f) * z * r + r;
-    float pc = ((2.443315711809948e-5f * z + -1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z;
-    pc = (pc - 0.5f * z) + 1.0f;
+    float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                    fmaf(-0.5f, z, 1.0f));
     float s, c;
     switch ((j >> 1) & 3u) {
         case 0: s = ps; c = pc; break;
@@ -106,8 +109,8 @@ static void m_sincos(float x, float *sn, float *cs) {
 }
 
 static float m_asin_poly(float z) {
-    return (((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
-           + 1.6666752422e-1f;
+    return fmaf(fmaf(fmaf(fmaf(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z, 7.4953002686e-2f), z,
+                1.6666752422e-1f);
 }
 
 static float m_acos(float x) {
@@ -115,23 +118,26 @@ static float m_acos(float x) {
     if (x > 0.5f) {
         float z = 0.5f * (1.0f - x);
         float s = sqrtf(z);
-        float r = m_asin_poly(z) * z * s + s;
+        float r = fmaf(m_asin_poly(z) * z, s, s);
         return r + r;
     }
     if (x < -0.5f) {
         float z = 0.5f * (1.0f + x);
         float s = sqrtf(z);
-        float r = m_asin_poly(z) * z * s + s;
+        float r = fmaf(m_asin_poly(z) * z, s, s);
         return PI_F - (r + r);
     }
     float z = x * x;
-    float r = m_asin_poly(z) * z * x + x;
+    float r = fmaf(m_asin_poly(z) * z, x, x);
     return PIO2_F - r;
 }
 
-/* cube root: exponent/3 bit guess, then two Halley steps y <- y*(y^3+2x)/(2y^3+x),
- * the second written as y + y*(x-y^3)/(2y^3+x) so its rounding error stays below one ulp. */
+/* cube root without a division: exponent/3 bit guess of r ~ a^(-1/3), two Newton steps
+ * r <- r (4/3 - a/3 r^3), y = a r^2 ~ a^(1/3), then one Newton step on y whose residual y^3 - a is
+ * formed to working precision (y^2 as an exact hi + lo pair): at most 0.52 ulp over every f32 in
+ * [2^-24, 2) against the f64 cbrt, and exact on the perfect cubes (tests/test_oracle_properties.py). */
 static float m_cbrt(float x) {
+    const float THIRD = 0.333333343267440796f, FOUR_THIRDS = 1.33333337306976318f;
     uint32_t ux = f2u(x);
     uint32_t sign = ux & 0x80000000u;
     uint32_t ua = ux & 0x7fffffffu;
@@ -139,11 +145,15 @@ static float m_cbrt(float x) {
     float a = u2f(ua);
     float scale = 1.0f;
     if (ua < 0x00800000u) { a = a * 16777216.0f; scale = 0.00390625f; ua = f2u(a); }  /* 2^24, 2^-8 */
-    float y = u2f(ua / 3u + 0x2a5137a0u);
-    float y3 = y * y * y;
-    y = y * ((y3 + (a + a)) / ((y3 + y3) + a));
-    y3 = y * y * y;
-    y = y + y * ((a - y3) / ((y3 + y3) + a));          /* same step, residual form: <= 1 ulp */
+    float r = u2f(0x54a21d2au - ua / 3u);
+    float a3 = a * THIRD;
+    r = r * fmaf(-a3, r * r * r, FOUR_THIRDS);
+    r = r * fmaf(-a3, r * r * r, FOUR_THIRDS);
+    float r2 = r * r;
+    float y = a * r2;
+    float hi = y * y, lo = fmaf(y, y, -hi);
+    float e = fmaf(hi, y, -a) + lo * y;
+    y = fmaf(-THIRD * e, r2, y);
     y = y * scale;
     return u2f(f2u(y) | sign);
 }
@@ -729,7 +739,7 @@ void orc_sample_batch(orc_world *w, const orc_sample_point *in, uint32_t n, orc_
 /* ------------------------------------------------------------------------------------------
  * Imager finalisation + Color (imager.rs:52-53; utils/image.rs:92-111)
  * ---------------------------------------------------------------------------------------- */
-/* trt-math v1 powf (the product's tiny-raytracer_amd/csrc/trt_pow.h states the same algorithm): the platform libm behind
+/* trt-math v2 powf (the product's tiny-raytracer_amd/csrc/trt_pow.h states the same algorithm): the platform libm behind
  * `powf` (image.rs:94-96) is pinned by nothing, so one algorithm is fixed: x^y = 2^k exp(r) with y log x = k ln2 + r,
  * in f64 with + - * / only, rounded once to f32.  log x: x = m 2^e, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1))
  * (odd series to s^23); exp r: Taylor to r^13.  Special cases as C99 pow. */

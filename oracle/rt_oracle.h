@@ -16,8 +16,8 @@
  * `rand::thread_rng`): BVH build/traversal, slab test, scatter functions, libm calls.
  * For those, two pieces are *defined here* and restated independently by the product:
  *   (1) "trt-rng v1": xoroshiro64* streams keyed by (seed, pixel, sample);
- *   (2) "trt-math v1": sin/cos/acos/cbrt as fixed f32 polynomial algorithms
- *       (no FMA contraction) so that host and device agree bit for bit.
+ *   (2) "trt-math v2": sin/cos/acos/cbrt as fixed f32 polynomial algorithms
+ *       (explicit fmaf only, no contraction) so that host and device agree bit for bit.
  * `orc_set_use_libm(1)` switches (2) to the platform libm, as the Rust original would
  * use, for statistical cross-checks.
  */
@@ -110,7 +110,7 @@ void orc_sample_batch(orc_world *, const orc_sample_point *in, uint32_t n, orc_s
 
 /* ---- Imager finalisation + Image/Color (imager.rs:52-53, utils/image.rs:92-111) ---- */
 void orc_tonemap_u8(const float *accum, uint32_t npixels, float gamma, uint8_t *rgb);
-float orc_powf(float x, float y);                 /* trt-math v1 powf (libm powf when orc_set_use_libm(1)) */
+float orc_powf(float x, float y);                 /* trt-math v2 powf (libm powf when orc_set_use_libm(1)) */
 float orc_gamma_correct(float c, float gamma);    /* Color::gamma_correction, one channel */
 
 /* ---- unit entry points for the reference's known-answer tests ---- */
@@ -132,7 +132,7 @@ orc_vec3 orc_vec3_refract(orc_vec3 v, orc_vec3 n, float eta);
 int orc_material_scatter(int kind, orc_vec3 albedo, float param, const orc_ray *ray_in,
                          const orc_hit_record *rec, uint32_t rng[2], orc_ray *scattered, orc_vec3 *attenuation);
 
-/* ---- trt-rng v1 / trt-math v1 ---- */
+/* ---- trt-rng v1 / trt-math v2 ---- */
 void orc_rng_seed(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t rng[2]);
 uint32_t orc_rng_next_u32(uint32_t rng[2]);
 float orc_rng_random(uint32_t rng[2]);                             /* [0,1)  utils/random.rs:11-13 */

@@ -173,7 +173,7 @@ def test_leaf_slots_are_scheduling_only(trt, monkeypatch, scene):
 
 def test_device_tonemap_is_bit_exact_against_the_oracle(trt, orc):
     """SURVEY 8 f1 on the device: the frame is rendered, gamma-corrected and quantised without leaving HBM.  Byte output:
-    the device frame must EQUAL the oracle's (orc_tonemap_u8) - both evaluate trt-math v1's powf (trt_pow.h / rt_oracle.c
+    the device frame must EQUAL the oracle's (orc_tonemap_u8) - both evaluate trt-math v2's powf (trt_pow.h / rt_oracle.c
     m_powf), as does the host form."""
     import torch
     dev = torch.device("cuda:0")

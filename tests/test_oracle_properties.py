@@ -1,6 +1,6 @@
 """Checks of the oracle beyond the reference's own KATs: the parts the reference leaves untested
 (BVH build/traversal, slab test, scatter functions, distributions) and the two pieces
-this project defines (trt-rng v1, trt-math v1)."""
+this project defines (trt-rng v1, trt-math v2)."""
 import ctypes as C
 import json
 import math
@@ -25,8 +25,9 @@ def _ulp_err(fn, ref, xs):
 
 
 def test_trt_math_close_to_libm(orc):
-    """trt-math v1 stands in for the platform libm the reference calls (vec3extend.rs:21-27): it has to be an
-    accurate sin/cos/acos/cbrt (a couple of ulp) on the ranges the path feeds it."""
+    """trt-math v2 stands in for the platform libm the reference calls (vec3extend.rs:21-27): it has to be an
+    accurate sin/cos/acos/cbrt (a couple of ulp) on the ranges the path feeds it, and the cube root - the one function
+    with no division left in it - exact on perfect cubes and below one ulp from subnormals up to 2^100."""
     rng = np.random.default_rng(0)
     theta = rng.uniform(0, 2 * math.pi, 40000).astype(np.float32)
     assert _ulp_err(orc.lib.orc_sinf, np.sin, theta) < 2.0
@@ -35,6 +36,15 @@ def test_trt_math_close_to_libm(orc):
     assert _ulp_err(orc.lib.orc_cbrtf, np.cbrt, rng.uniform(0, 1, 40000).astype(np.float32)) < 1.0
     assert _ulp_err(orc.lib.orc_cbrtf, np.cbrt, (np.arange(1, 20000) / 2.0 ** 23).astype(np.float32)) < 1.0
     assert orc.lib.orc_cbrtf(0.0) == 0.0 and orc.lib.orc_cbrtf(1.0) == 1.0 and orc.lib.orc_cbrtf(-27.0) == -3.0
+    for k in range(1, 200):                                            # perfect cubes (and their 2^-3n scalings) come out exact
+        assert orc.lib.orc_cbrtf(float(k ** 3)) == float(k) and orc.lib.orc_cbrtf(-float(k ** 3) / 512.0) == -k / 8.0, k
+    wide = np.exp2(rng.uniform(-149, 100, 40000)).astype(np.float32)   # subnormals .. 2^100
+    assert _ulp_err(orc.lib.orc_cbrtf, np.cbrt, wide[wide > 0]) < 1.0
+    assert _ulp_err(orc.lib.orc_cbrtf, np.cbrt, -wide[wide > 0]) < 1.0
+    assert math.isinf(orc.lib.orc_cbrtf(float("inf"))) and math.isnan(orc.lib.orc_cbrtf(float("nan")))
+    far = rng.uniform(-8000, 8000, 40000).astype(np.float32)           # whole reduction range: absolute error (zeros of sin lie inside)
+    assert np.abs(np.array([orc.lib.orc_sinf(float(x)) for x in far]) - np.sin(far.astype(np.float64))).max() < 2.5e-7
+    assert np.abs(np.array([orc.lib.orc_cosf(float(x)) for x in far]) - np.cos(far.astype(np.float64))).max() < 2.5e-7
     assert orc.lib.orc_acosf(1.0) == 0.0 and abs(orc.lib.orc_acosf(-1.0) - math.pi) < 1e-6
     assert math.isnan(orc.lib.orc_acosf(1.5))
 
@@ -189,7 +199,7 @@ def test_oracle_matches_reference_renders_statistically(orc, trt):
 
 
 def test_own_math_vs_libm_mode_agree_statistically(orc, trt):
-    """Swapping trt-math v1 for the platform libm (what the Rust original calls) leaves the frame's statistics alone."""
+    """Swapping trt-math v2 for the platform libm (what the Rust original calls) leaves the frame's statistics alone."""
     desc = trt.scenes.cornell(60, 60)
     w, cam = orc.world_from_description(desc)
     a, _ = orc.render(w, cam, 64, 12, desc["background"], nthreads=8)
@@ -202,7 +212,7 @@ def test_own_math_vs_libm_mode_agree_statistically(orc, trt):
 
 
 def test_powf_v1_is_the_correctly_rounded_power_almost_everywhere(orc):
-    """trt-math v1 powf (rt_oracle.c m_powf, f64 inside, one rounding to f32) against numpy's f64 power rounded to f32:
+    """trt-math v2 powf (rt_oracle.c m_powf, f64 inside, one rounding to f32) against numpy's f64 power rounded to f32:
     identical on this sample (the f64 result carries ~1e-14 relative error, so about one input in 10^6 may round the other
     way), and C99's special cases.  The reference's libm powf (image.rs:94-96) is pinned by none of its tests."""
     rng = np.random.default_rng(5)
@@ -234,7 +244,7 @@ def test_powf_v1_is_the_correctly_rounded_power_almost_everywhere(orc):
 
 
 def test_u8_frame_of_trt_powf_against_platform_libm_powf(orc, trt):
-    """host tonemap, device tonemap and oracle share ONE powf (trt-math v1), so their byte-exact agreement compares the
+    """host tonemap, device tonemap and oracle share ONE powf (trt-math v2), so their byte-exact agreement compares the
     algorithm with itself; the reference calls the platform's libm powf (utils/image.rs:94-96).  Here the quantised frame of the
     product's tonemap is compared with the oracle's in LIBM mode (glibc powf) on a rendered frame and on 2 M synthetic channel
     values: a channel may differ by one least-significant bit (where the two powf round differently right at a quantisation step)
@@ -247,7 +257,7 @@ def test_u8_frame_of_trt_powf_against_platform_libm_powf(orc, trt):
     synth = np.resize(synth, (len(synth) // 3) * 3)
     for values in (frame.reshape(-1), synth):
         img = trt.Image(values.reshape(-1, 1, 3).copy())
-        mine = img.to_u8().reshape(-1).astype(np.int32)                 # libtinyrt's host tonemap (trt-math v1 powf), no GPU needed
+        mine = img.to_u8().reshape(-1).astype(np.int32)                 # libtinyrt's host tonemap (trt-math v2 powf), no GPU needed
         orc.lib.orc_set_use_libm(1)
         try:
             libm = orc.tonemap_u8(values.reshape(-1, 3)).reshape(-1).astype(np.int32)

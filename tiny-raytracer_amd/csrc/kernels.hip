@@ -205,7 +205,7 @@ hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in,
 // Imager finalisation on the device: Color::gamma_correction + From<Color> for Rgb<u8>
 // (utils/image.rs:92-111): c^(1/gamma), clamp to [0, 0.999], * 255, truncate; NaN -> 0.  Elementwise and HBM-bound:
 // 12 bytes read + 3 written per pixel, four channels per lane (one 16-byte load, one 4-byte store).
-// c^(1/gamma) is trt-math v1's powf (trt_pow.h): the same function the host form (scene_host.cpp tonemap_u8) and the CPU
+// c^(1/gamma) is trt-math v2's powf (trt_pow.h): the same function the host form (scene_host.cpp tonemap_u8) and the CPU
 // oracle evaluate, so the three u8 frames are equal byte for byte (tests compare them exactly).
 // ------------------------------------------------------------------------------------------------
 TRT_DEV uint32_t quantise_channel(float c, float inv_gamma) { return (uint32_t)tm_quantise_channel(c, inv_gamma); }

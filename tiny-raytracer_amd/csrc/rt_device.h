@@ -9,7 +9,7 @@
 // Two pieces have no counterpart that could be matched bit for bit in the reference and are
 // specified by this project: "trt-rng v1" (xoroshiro64* streams keyed by seed,
 // pixel and sample, standing in for the unseeded rand::thread_rng of utils/random.rs:15-18)
-// and "trt-math v1" (fixed polynomial sin/cos/acos/cbrt standing in for the platform libm
+// and "trt-math v2" (fixed polynomial sin/cos/acos/cbrt standing in for the platform libm
 // behind vec3extend.rs:21-27).
 #pragma once
 
@@ -98,7 +98,9 @@ TRT_DEV V3 refract(V3 v, V3 n, float eta) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// trt-math v1
+// trt-math v2: fma Horner chains over v1's reductions and polynomials, a cube root without
+// divisions.  The operation order is the specification - the CPU checker states the same sequence - and
+// -ffp-contract=off means only the fma written here fuses.
 // ------------------------------------------------------------------------------------------------
 // sin and cos of x, |x| < 8192: octant reduction by a three-term split of pi/4, then
 // degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4].
@@ -110,11 +112,11 @@ TRT_DEV void dm_sincos(float x, float& sn, float& cs) {
     uint32_t j = (uint32_t)(ax * FOPI);
     j = (j + 1u) & ~1u;
     float y = (float)j;
-    float r = ((ax - y * DP1) - y * DP2) - y * DP3;
+    float r = __builtin_fmaf(-y, DP3, __builtin_fmaf(-y, DP2, __builtin_fmaf(-y, DP1, ax)));
     float z = r * r;
-    float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z + -1.6666654611e-1f) * z * r + r;
-    float pc = ((2.443315711809948e-5f * z + -1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z;
-    pc = (pc - 0.5f * z) + 1.0f;
+    float ps = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+    float pc = __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f) * z, z,
+                              __builtin_fmaf(-0.5f, z, 1.0f));
     uint32_t q = (j >> 1) & 3u;
     float s = (q & 1u) ? pc : ps;
     float c = (q & 1u) ? ps : pc;
@@ -125,8 +127,8 @@ TRT_DEV void dm_sincos(float x, float& sn, float& cs) {
 }
 
 TRT_DEV float dm_asin_poly(float z) {
-    return (((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z
-           + 1.6666752422e-1f;
+    return __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(__builtin_fmaf(4.2163199048e-2f, z, 2.4181311049e-2f), z, 4.5470025998e-2f), z,
+                                         7.4953002686e-2f), z, 1.6666752422e-1f);
 }
 
 // Branch-free form of the three-range evaluation (|x| <= 0.5: pi/2 - asin(x); x > 0.5: 2 asin(sqrt((1-x)/2));
@@ -140,13 +142,15 @@ TRT_DEV float dm_acos(float x) {
     const float z = big ? 0.5f * (1.0f - ax) : x * x;
     // z <= 0.25; it is 0 for x = +-1 and tiny next to it: the short sqrt applies from 2^-80 up
     const float w = big ? (__builtin_expect(z >= 8.271806125530277e-25f, 1) ? sqrt_in_range(z) : __builtin_sqrtf(z)) : x;
-    const float r = dm_asin_poly(z) * z * w + w;
+    const float r = __builtin_fmaf(dm_asin_poly(z) * z, w, w);
     const float two_r = r + r;
     return big ? (x > 0.0f ? two_r : PI_F - two_r) : PIO2_F - r;
 }
 
-// cube root: exponent/3 bit guess, two Halley steps; the second in residual form (< 1 ulp).
+// cube root without a division: bit guess of r ~ a^(-1/3), two Newton steps on r, y = a r^2, one Newton step on y with
+// the residual y^3 - a formed to working precision (<= 0.52 ulp, exact on perfect cubes).
 TRT_DEV float dm_cbrt(float x) {
+    const float THIRD = 0.333333343267440796f, FOUR_THIRDS = 1.33333337306976318f;
     uint32_t ux = __float_as_uint(x);
     uint32_t sign = ux & 0x80000000u;
     uint32_t ua = ux & 0x7fffffffu;
@@ -154,11 +158,15 @@ TRT_DEV float dm_cbrt(float x) {
     float a = __uint_as_float(ua);
     float scale = 1.0f;
     if (ua < 0x00800000u) { a = a * 16777216.0f; scale = 0.00390625f; ua = __float_as_uint(a); }
-    float y = __uint_as_float(ua / 3u + 0x2a5137a0u);
-    float y3 = y * y * y;
-    y = y * ((y3 + (a + a)) / ((y3 + y3) + a));
-    y3 = y * y * y;
-    y = y + y * ((a - y3) / ((y3 + y3) + a));
+    float r = __uint_as_float(0x54a21d2au - ua / 3u);
+    const float a3 = a * THIRD;
+    r = r * __builtin_fmaf(-a3, r * r * r, FOUR_THIRDS);
+    r = r * __builtin_fmaf(-a3, r * r * r, FOUR_THIRDS);
+    const float r2 = r * r;
+    float y = a * r2;
+    const float hi = y * y, lo = __builtin_fmaf(y, y, -hi);
+    const float e = __builtin_fmaf(hi, y, -a) + lo * y;
+    y = __builtin_fmaf(-THIRD * e, r2, y);
     y = y * scale;
     return __uint_as_float(__float_as_uint(y) | sign);
 }

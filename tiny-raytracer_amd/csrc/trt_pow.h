@@ -1,4 +1,4 @@
-// trt_pow.h — trt-math v1 `powf`, the one function the Imager's finalisation needs
+// trt_pow.h — trt-math v2 `powf`, the one function the Imager's finalisation needs
 // (Color::gamma_correction, utils/image.rs:92-98: `c.powf(1.0 / gamma)`).
 //
 // The reference calls the platform libm through Rust's std, which no test of the reference pins and which the GPU
