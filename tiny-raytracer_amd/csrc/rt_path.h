@@ -304,6 +304,83 @@ TRT_DEV void trav_unpark(const float2* stk, Trav& tr) {
     tr.prim_best = __float_as_uint(b.x);
 }
 
+// The box-step loop of walk_fast_lds, written by hand (round 3).  The loop the compiler builds from the C++ below spends 22 scalar
+// instructions per trip on 29 vector ones - the structuriser's exec-mask bookkeeping for `while (a && b) { ...; if (c) push; if (d) break; }` -
+// and the scalar unit issues one instruction per ~4.8 cycles per SIMD (tools/micro/salu_rate.hip: 24 scalar instructions ride free on 32
+// vector ones, 32 do not), so the trip was bound by its scalar half.  Here a trip is 29 vector + 10 scalar instructions: the lanes that
+// leave the loop (walk over, or leaf stack full) are dropped from exec for good, a leaf is put aside under a saved exec mask, and the
+// stragglers exit is one s_bcnt1 + compare.  Same operations on the same values as slab_fast_entry + the C++ loop body (min / max of
+// non-NaN values are exact, so their order is free); exec is restored on exit.  v48-v57 are fixed because a 128-bit LDS read needs four
+// consecutive registers and inline-asm operands cannot be taken apart.  Returns the lane's new stack top.
+#ifndef TRT_ASM_BOX_LOOP
+#define TRT_ASM_BOX_LOOP 1
+#endif
+constexpr bool kAsmBoxLoop = TRT_ASM_BOX_LOOP != 0;
+
+TRT_DEV uint32_t lds_offset(const void* p) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p; }
+
+TRT_DEV float2* box_loop_lds(Trav& tr, const V3& o, float2* stk, float2* limit, uint32_t n, uint32_t few) {
+    const uint32_t stk_off = lds_offset(stk);
+    uint32_t top = stk_off;
+    const uint32_t lim = lds_offset(limit), base = lds_offset(g_lds);
+    unsigned long long saved, m0, m1;
+    uint32_t cnt;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "1:\n"
+        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < n
+        "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // top != limit
+        "s_and_b64 vcc, vcc, %[m0]\n"
+        "s_and_b64 exec, exec, vcc\n"                        // lanes that fail either leave the loop for good
+        "s_cbranch_scc0 2f\n"
+        "v_lshl_add_u32 v52, %[i], 5, %[base]\n"
+        "ds_read_b128 v[48:51], v52\n"                       // lo.x lo.y lo.z hi.x
+        "ds_read_b128 v[52:55], v52 offset:16\n"             // hi.y hi.z skip link
+        "s_waitcnt lgkmcnt(1)\n"
+        "v_sub_f32_e32 v48, v48, %[ox]\n"
+        "v_sub_f32_e32 v51, v51, %[ox]\n"
+        "v_sub_f32_e32 v49, v49, %[oy]\n"
+        "v_sub_f32_e32 v50, v50, %[oz]\n"
+        "v_mul_f32_e32 v48, v48, %[ix]\n"
+        "v_mul_f32_e32 v51, v51, %[ix]\n"
+        "v_mul_f32_e32 v49, v49, %[iy]\n"
+        "v_mul_f32_e32 v50, v50, %[iz]\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        "v_sub_f32_e32 v52, v52, %[oy]\n"
+        "v_sub_f32_e32 v53, v53, %[oz]\n"
+        "v_mul_f32_e32 v52, v52, %[iy]\n"
+        "v_mul_f32_e32 v53, v53, %[iz]\n"
+        "v_min_f32_e32 v56, v48, v51\n"                      // entry x
+        "v_max_f32_e32 v48, v48, v51\n"                      // exit x
+        "v_min_f32_e32 v57, v49, v52\n"
+        "v_max_f32_e32 v49, v49, v52\n"
+        "v_max_f32_e32 v56, v56, v57\n"
+        "v_min_f32_e32 v57, v50, v53\n"
+        "v_max_f32_e32 v50, v50, v53\n"
+        "v_min_f32_e32 v48, v48, v49\n"
+        "v_max3_f32 v56, v56, v57, %[tmin]\n"                // start = max(t_min, entries)
+        "v_min3_f32 v48, %[tb], v48, v50\n"                  // end = min(t_best, exits)
+        "v_cmp_nle_f32_e32 vcc, v48, v56\n"                  // pass = !(end <= start)
+        "v_cmp_gt_i32_e64 %[m0], 0, v55\n"                   // inner node: NODE_INNER_BIT is the sign bit of the link
+        "s_and_b64 %[m1], vcc, %[m0]\n"
+        "v_cndmask_b32_e64 %[i], v54, |v55|, %[m1]\n"        // descend (link without the bit), or skip (a leaf's skip is its successor)
+        "s_andn2_b64 %[m1], vcc, %[m0]\n"                    // a leaf whose box passes:
+        "s_and_saveexec_b64 %[m0], %[m1]\n"
+        "ds_write2_b32 %[top], v55, v56 offset1:1\n"         //   put (leaf, start) aside (two dwords: an odd-aligned register pair is no tuple)
+        "v_add_u32_e32 %[top], 0x200, %[top]\n"
+        "s_mov_b64 exec, %[m0]\n"
+        "s_bcnt1_i32_b64 %[cnt], exec\n"                     // resumable walk: go on only while more than `few` lanes still step boxes
+        "s_cmp_gt_u32 %[cnt], %[few]\n"
+        "s_cbranch_scc1 1b\n"
+        "2:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [i] "+v"(tr.i), [top] "+v"(top), [sv] "=&s"(saved), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt)
+        : [n] "s"(n), [few] "s"(few), [base] "s"(base), [lim] "v"(lim), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(tr.inv.x),
+          [iy] "v"(tr.inv.y), [iz] "v"(tr.inv.z), [tb] "v"(tr.t_best), [tmin] "s"(kTMin)
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57");
+    return stk + ((top - stk_off) >> 3);
+}
+
 // The same walk with the postponed leaves in LDS instead of registers: `stk` is this lane's slot 0, slot k lives at
 // stk[64 * k] (one 8-byte (leaf, start) pair per lane and slot, lane-contiguous: conflict-free ds_write_b64 /
 // ds_read_b64).  Putting a leaf aside costs one address, one LDS write and one add instead of the compare/select
@@ -325,6 +402,9 @@ TRT_DEV bool walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
     const uint32_t few = stragglers < entered ? stragglers : entered - 1u;
     for (;;) {
         float2* top = stk;
+        if constexpr (kAsmBoxLoop && !STATS && MODE == MODE_LDS) {
+            top = box_loop_lds(tr, ray.o, stk, limit, n, few);
+        } else
         while (tr.i < n && top != limit) {
             float4 na, nb;
             sc.node(tr.i, na, nb);
