@@ -493,6 +493,77 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
 constexpr uint32_t kCompactLeafBit = 0x80000000u;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+// The box-step loop of walk_compact by hand, like box_loop_lds (same reasons, same conventions): one 16-byte node per trip through the
+// scalar-base form of global_load (a 32-bit byte offset in ONE register instead of a 64-bit address in two), 37 vector + 10 scalar
+// instructions per trip instead of 38 + 21.
+TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict__ nodes16, float2* stk, float2* limit, uint32_t n, uint32_t few) {
+    const uint32_t stk_off = lds_offset(stk);
+    uint32_t top = stk_off;
+    const uint32_t lim = lds_offset(limit);
+    unsigned long long saved, m0, m1;
+    uint32_t cnt;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "1:\n"
+        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < n
+        "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // top != limit
+        "s_and_b64 vcc, vcc, %[m0]\n"
+        "s_and_b64 exec, exec, vcc\n"
+        "s_cbranch_scc0 2f\n"
+        "v_lshlrev_b32_e32 v52, 4, %[i]\n"
+        "global_load_dwordx4 v[48:51], v52, %[nodes]\n"      // (lo.x lo.y) (lo.z hi.x) (hi.y hi.z) as f16 pairs, link
+        "s_waitcnt vmcnt(0)\n"
+        "v_cvt_f32_f16_e32 v52, v48\n"                                                                    // lo.x
+        "v_cvt_f32_f16_sdwa v48, v48 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // lo.y
+        "v_cvt_f32_f16_e32 v53, v49\n"                                                                    // lo.z
+        "v_cvt_f32_f16_sdwa v49, v49 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // hi.x
+        "v_cvt_f32_f16_e32 v54, v50\n"                                                                    // hi.y
+        "v_cvt_f32_f16_sdwa v50, v50 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // hi.z
+        "v_sub_f32_e32 v52, v52, %[ox]\n"
+        "v_sub_f32_e32 v49, v49, %[ox]\n"
+        "v_sub_f32_e32 v48, v48, %[oy]\n"
+        "v_sub_f32_e32 v54, v54, %[oy]\n"
+        "v_sub_f32_e32 v53, v53, %[oz]\n"
+        "v_sub_f32_e32 v50, v50, %[oz]\n"
+        "v_mul_f32_e32 v52, v52, %[ix]\n"
+        "v_mul_f32_e32 v49, v49, %[ix]\n"
+        "v_mul_f32_e32 v48, v48, %[iy]\n"
+        "v_mul_f32_e32 v54, v54, %[iy]\n"
+        "v_mul_f32_e32 v53, v53, %[iz]\n"
+        "v_mul_f32_e32 v50, v50, %[iz]\n"
+        "v_min_f32_e32 v55, v52, v49\n"                      // entry x
+        "v_max_f32_e32 v52, v52, v49\n"                      // exit x
+        "v_min_f32_e32 v56, v48, v54\n"
+        "v_max_f32_e32 v48, v48, v54\n"
+        "v_max_f32_e32 v55, v55, v56\n"
+        "v_min_f32_e32 v56, v53, v50\n"
+        "v_max_f32_e32 v53, v53, v50\n"
+        "v_min_f32_e32 v52, v52, v48\n"
+        "v_max3_f32 v55, v55, v56, %[tmin]\n"                // start
+        "v_min3_f32 v52, %[tb], v52, v53\n"                  // end
+        "v_cmp_nle_f32_e32 vcc, v52, v55\n"                  // pass = !(end <= start)
+        "v_cmp_gt_i32_e64 %[m0], 0, v51\n"                   // leaf: kCompactLeafBit is the sign bit of the fourth word
+        "s_or_b64 %[m1], vcc, %[m0]\n"
+        "v_add_u32_e32 v56, 1, %[i]\n"
+        "v_cndmask_b32_e64 %[i], v51, v56, %[m1]\n"          // first child / a leaf's successor, or the skip link
+        "s_and_b64 %[m1], vcc, %[m0]\n"                      // a leaf whose coarse box passes:
+        "s_and_saveexec_b64 %[m0], %[m1]\n"
+        "v_and_b32_e32 v54, 0x7fffffff, v51\n"
+        "ds_write2_b32 %[top], v54, v55 offset1:1\n"         //   put (leaf sequence number, coarse start) aside
+        "v_add_u32_e32 %[top], 0x200, %[top]\n"
+        "s_mov_b64 exec, %[m0]\n"
+        "s_bcnt1_i32_b64 %[cnt], exec\n"
+        "s_cmp_gt_u32 %[cnt], %[few]\n"
+        "s_cbranch_scc1 1b\n"
+        "2:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        : [i] "+v"(tr.i), [top] "+v"(top), [sv] "=&s"(saved), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt)
+        : [n] "s"(n), [few] "s"(few), [nodes] "s"(nodes16), [lim] "v"(lim), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(tr.inv.x),
+          [iy] "v"(tr.inv.y), [iz] "v"(tr.inv.z), [tb] "v"(tr.t_best), [tmin] "s"(kTMin)
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
+    return stk + ((top - stk_off) >> 3);
+}
+
 // Resumable: with `stragglers` > 0 the function returns false - walk unfinished, tr holds where it stands - as soon as at most
 // that many lanes of the wave are still walking while others have finished (`entered` = lanes that came in); the leaf stack is
 // empty at that point, so nothing but tr has to be kept.  The caller shades the finished lanes, gives them their next ray, and
@@ -513,6 +584,9 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
         // there when the walk goes on to it - the successor IS the next node whenever the box passes or the node is a leaf.  It
         // shortens the chain of dependent loads by a third, and is 15 % slower on the 100 k-sphere scene: twice the vector-memory
         // instructions, and the second step runs with about half of the lanes.)
+        if constexpr (kAsmBoxLoop && !STATS) {
+            top = box_loop_compact(tr, ray.o, nodes16, stk, limit, n, few);
+        } else
         while (tr.i < n && top != limit) {
             const uint4 q = nodes16[tr.i];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
