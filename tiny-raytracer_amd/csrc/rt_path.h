@@ -569,8 +569,8 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
 // empty at that point, so nothing but tr has to be kept.  The caller shades the finished lanes, gives them their next ray, and
 // calls again: the stragglers go on from tr.i while the new walks start beside them, instead of 50 lanes idling through the
 // last third of the trips behind a few long walks (100 k spheres: 324 trips per round for 222 box steps per ray).  Measured:
-// +10 % on that scene; the same for the LDS-resident tree walk (random-spheres) gains nothing - the carried walk state and
-// the extra rounds cancel it - so walk_fast_lds is not resumable.
+// +10 % on that scene in round 2; since round 3 (exit test inside the box-step loop, walk state parked in the leaf stack) the
+// LDS-resident tree walk is resumable too (walk_fast_lds: random-spheres +10 %).
 template <int MODE, bool STATS>
 TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
                           const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots, uint32_t stragglers = 0u,

@@ -7,11 +7,14 @@
 # leaves the runtime's own "Memory access fault by GPU node ..." line there too: one normal pass records WHAT a failure was.
 # (Round 2's version piped pytest through `tail -1` and lost exactly that when `TRT_STREAM_MINW=8` dumped core once.)
 # The script stops at the first knob that does not pass: after a fault, no further GPU work in the same call.
+# If build/libtinyrt_cxxloops.so exists (make -C tiny-raytracer_amd/csrc cxxloops: the C++ box-step loops instead of the hand-written ones),
+# the suite also runs once on that build.
 out=gpurun_out/knobs; mkdir -p $out
+[ -f build/libtinyrt_cxxloops.so ] && TRT_EXTRA_KNOBS="$TRT_EXTRA_KNOBS TRT_LIB_PATH=$PWD/build/libtinyrt_cxxloops.so"
 skip='not leaf_slots_are and not lockstep and not global_memory_walks and not full_size_schedules and not full_baseline and not cfg5 and not at_size'
 for e in "TRT_RAY_POOL=0" "TRT_FLAT_WALK=0" "TRT_LDS_LEAF_STACK=0" "TRT_COMPACT_NODES=0" "TRT_STREAM_MINW=5" "TRT_STREAM_MINW=7" "TRT_STREAM_MINW=8" "TRT_LEAF_SLOTS=1" "TRT_LEAF_SLOTS=2" \
          "TRT_RUNTIME_WALK=1" "TRT_BIG_THREADS=512" "TRT_STRAGGLERS=0" "TRT_STRAGGLERS=40" "TRT_LDS_STRAGGLERS=0" "TRT_LDS_STRAGGLERS=24" "TRT_CULL_PRUNE=0.8" $TRT_EXTRA_KNOBS; do
-  log=$out/$e.log
+  log=$out/$(echo "$e" | tr "/" "_").log
   env $e AMD_LOG_LEVEL=1 PYTHONFAULTHANDLER=1 timeout -k 10 300 python3 -X faulthandler -m pytest tests -x -q -m gpu -k "$skip" > "$log" 2>&1
   rc=$?
   echo "== $e: rc=$rc $(tail -1 "$log")"
