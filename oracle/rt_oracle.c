@@ -13,6 +13,7 @@
 #include <math.h>
 #include <pthread.h>
 #include <stdatomic.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -78,6 +79,17 @@ static int v3_eq(vec3 a, vec3 b) {
  * ---------------------------------------------------------------------------------------- */
 static int g_use_libm = 0;
 void orc_set_use_libm(int on) { g_use_libm = on; }
+
+/* The build passes -mfma (fmaf as one instruction): refuse to load on a CPU without it instead of dying on an illegal instruction. */
+__attribute__((constructor)) static void orc_require_fma(void) {
+#if defined(__x86_64__) && defined(__FMA__)
+    __builtin_cpu_init();
+    if (!__builtin_cpu_supports("fma")) {
+        fprintf(stderr, "liboracle: this build uses FMA3 instructions (-mfma) and the CPU has none; rebuild oracle/ with CFLAGS without -mfma\n");
+        abort();
+    }
+#endif
+}
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
