@@ -158,6 +158,23 @@ def test_short_sqrt_is_sqrtf_on_every_float_in_range(tmp_path):
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
 
 
+def test_device_math_equals_the_oracles_on_every_input_the_path_can_produce(tmp_path, orc):
+    """trt-math v2 on the device (rt_device.h) against the CPU checker's statement of it, EXHAUSTIVELY over the path's input domain:
+    random::<f32>() has 2^23 values, and vec3extend.rs:15-30 turns one each into theta = 2 pi u, phi = acos(1 - 2u), r = cbrt(u) -
+    tests/native/math_exhaustive.hip evaluates sin / cos(theta), acos, sin / cos(phi) and cbrt for all of them on the GPU, and the
+    composed random_in_unit_sphere / random_unit_vector on 2^22 generator states, and compares every float with liboracle's, bit for bit."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "math_exhaustive")
+    odir = os.path.join(root, "oracle")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-I", os.path.join(root, "tiny-raytracer_amd", "csrc"),
+                    "-I", odir, "-o", exe, os.path.join(root, "tests", "native", "math_exhaustive.hip"), "-L", odir, "-loracle",
+                    "-Wl,-rpath," + odir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.parametrize("n_prims", [400, 560])
 def test_medium_mixed_scenes_in_lds(trt, orc, n_prims):
     """Mixed spheres and quads with an LDS-resident hot part above 20 KB: the regime of the 768-lane workgroups with an LDS leaf
