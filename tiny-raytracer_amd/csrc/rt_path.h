@@ -432,6 +432,67 @@ TRT_DEV bool walk_fast_lds(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, C
     }
 }
 
+// The box-step loop of walk_flat by hand (round 3; conventions of box_loop_lds).  The leaf pair under test lives in s[36:51] - sixteen fixed
+// SGPRs, because a 64-byte scalar load needs an aligned tuple and inline-asm operands cannot be taken apart - and the next pair is requested
+// as soon as the last value of the current one has been read (the link of the second leaf is copied out first); the wave's other lanes'
+// work covers the rest of that load's latency.  25 vector instructions per box (23 for the slab test + the link copy and the stack-top add
+// under the push mask) and 6.5 scalar ones, against 26 + 12.5 from the C++ loop below.  `i` is the next leaf to test (wave-uniform, in and out);
+// the loop ends when i == n or when some lane cannot hold another pair of leaves.  Returns the lane's new stack top.
+#define TRT_FLAT_BOX(LOX, LOY, LOZ, HIX, HIY, HIZ)                                                                                        \
+    "v_sub_f32_e32 %[t0], " LOX ", %[ox]\n v_sub_f32_e32 %[t1], " HIX ", %[ox]\n v_sub_f32_e32 %[t2], " LOY ", %[oy]\n"                   \
+    "v_sub_f32_e32 %[t3], " HIY ", %[oy]\n v_mul_f32_e32 %[t0], %[ix], %[t0]\n v_mul_f32_e32 %[t1], %[ix], %[t1]\n"                       \
+    "v_mul_f32_e32 %[t2], %[iy], %[t2]\n v_mul_f32_e32 %[t3], %[iy], %[t3]\n v_sub_f32_e32 %[t4], " LOZ ", %[oz]\n"                      \
+    "v_sub_f32_e32 %[t5], " HIZ ", %[oz]\n v_mul_f32_e32 %[t4], %[iz], %[t4]\n v_mul_f32_e32 %[t5], %[iz], %[t5]\n"                      \
+    "v_min_f32_e32 %[st], %[t0], %[t1]\n v_max_f32_e32 %[t0], %[t0], %[t1]\n v_min_f32_e32 %[t1], %[t2], %[t3]\n"                        \
+    "v_max_f32_e32 %[t2], %[t2], %[t3]\n v_max_f32_e32 %[st], %[st], %[t1]\n v_min_f32_e32 %[t1], %[t4], %[t5]\n"                        \
+    "v_max_f32_e32 %[t4], %[t4], %[t5]\n v_min_f32_e32 %[t0], %[t0], %[t2]\n v_max3_f32 %[st], %[st], %[t1], %[tmin]\n"                  \
+    "v_min3_f32 %[t0], %[tb], %[t0], %[t4]\n v_cmp_nle_f32_e32 vcc, %[t0], %[st]\n"
+
+TRT_DEV float2* box_loop_flat(const Trav& tr, const V3& o, const float4* __restrict__ leaf_list, uint32_t& i, uint32_t n, float2* stk, float2* limit) {
+    const uint32_t stk_off = lds_offset(stk);
+    uint32_t top = stk_off;
+    const uint32_t lim = lds_offset(limit);
+    unsigned long long m;
+    uint32_t off;
+    float t0, t1, t2, t3, t4, t5, st, lk;
+    asm volatile(
+        "s_lshl_b32 %[off], %[i], 5\n"                              // a leaf is 32 bytes: (lo.x lo.y lo.z hi.x) (hi.y hi.z skip link)
+        "s_load_dwordx16 s[36:51], %[list], %[off]\n"               // leaves i and i + 1 (the list is padded: scene.h kLeafListPad)
+        "1:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        TRT_FLAT_BOX("s36", "s37", "s38", "s39", "s40", "s41")
+        "s_and_saveexec_b64 %[m], vcc\n"                            // box passes: put (leaf, start) aside
+        "v_mov_b32_e32 %[lk], s43\n"
+        "ds_write2_b32 %[top], %[lk], %[st] offset1:1\n"
+        "v_add_u32_e32 %[top], 0x200, %[top]\n"
+        "s_mov_b64 exec, %[m]\n"
+        "s_add_u32 %[i], %[i], 1\n"
+        "s_cmp_ge_u32 %[i], %[n]\n"
+        "s_cbranch_scc1 2f\n"                                       // an odd last leaf
+        TRT_FLAT_BOX("s44", "s45", "s46", "s47", "s48", "s49")
+        "v_mov_b32_e32 %[lk], s51\n"                                // last value of this pair: the next one may come
+        "s_add_u32 %[off], %[off], 64\n"
+        "s_load_dwordx16 s[36:51], %[list], %[off]\n"
+        "s_and_saveexec_b64 %[m], vcc\n"
+        "ds_write2_b32 %[top], %[lk], %[st] offset1:1\n"
+        "v_add_u32_e32 %[top], 0x200, %[top]\n"
+        "s_mov_b64 exec, %[m]\n"
+        "s_add_u32 %[i], %[i], 1\n"
+        "v_cmp_gt_u32_e32 vcc, %[top], %[lim]\n"                    // some lane cannot hold another pair: test what is pending
+        "s_cmp_lg_u64 vcc, 0\n"
+        "s_cbranch_scc1 2f\n"
+        "s_cmp_lt_u32 %[i], %[n]\n"
+        "s_cbranch_scc1 1b\n"
+        "2:\n"
+        "s_waitcnt lgkmcnt(0)\n"                                    // nothing may land in s[36:51] after the block
+        : [i] "+s"(i), [top] "+v"(top), [m] "=&s"(m), [off] "=&s"(off), [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3),
+          [t4] "=&v"(t4), [t5] "=&v"(t5), [st] "=&v"(st), [lk] "=&v"(lk)
+        : [n] "s"(n), [list] "s"(leaf_list), [lim] "v"(lim), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(tr.inv.x), [iy] "v"(tr.inv.y),
+          [iz] "v"(tr.inv.z), [tb] "v"(tr.t_best), [tmin] "s"(kTMin)
+        : "vcc", "scc", "memory", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");
+    return stk + ((top - stk_off) >> 3);
+}
+
 // Scenes with a handful of primitives (SceneLayout::flat_walk): no tree at all.  Every lane of the wave steps the SAME
 // leaf box in the same trip - the list of leaves in walk order - so the node is wave-uniform: it comes through the
 // scalar cache into SGPRs (`leaf_list` must be a __restrict__ kernel argument for that), there is no per-lane address,
@@ -448,6 +509,14 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
                        float2* stk, uint32_t slots) {
     const uint32_t n = sc.L.n_leaves;                    // >= 1
     uint32_t i = 0;                                      // wave-uniform
+    if constexpr (kAsmBoxLoop && !STATS) {
+        float2* const lim = stk + 64u * (slots - 2u);
+        do {
+            float2* const top = box_loop_flat(tr, ray.o, leaf_list, i, n, stk, lim);
+            leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
+        } while (i < n);
+        return;
+    }
     const float4* __restrict__ pair = leaf_list;         // wave-uniform: the pair under test; the list is padded (scene.h kLeafListPad), so
                                                          // reading one pair ahead needs no clamping: ONE 64-byte scalar load per trip
     float4 a0 = pair[0], b0 = pair[1], a1 = pair[2], b1 = pair[3];
