@@ -513,7 +513,9 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
         float2* const lim = stk + 64u * (slots - 2u);
         do {
             float2* const top = box_loop_flat(tr, ray.o, leaf_list, i, n, stk, lim);
+            TRT_CLK(ctr, 1);
             leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
+            TRT_CLK(ctr, 2);
         } while (i < n);
         return;
     }
