@@ -86,7 +86,7 @@ int trt_scene_create(const trt_world *w, trt_scene **out);
 void trt_scene_destroy(trt_scene *s);
 /* The scene handle caches device resources per device: the uploaded scene, render scratch ("workspaces": up to 8 per device,
  * e.g. 3.2 GB each at 2048x2048) and, for the blocking entry points, contexts (stream, events, counters, a device frame).
- * Idle scratch beyond 8 GiB per device (environment TRT_SCRATCH_CAP_MB) is freed when a render ends; this call frees ALL idle
+ * Idle scratch beyond 32 GiB per device (environment TRT_SCRATCH_CAP_MB) is freed when a render ends; this call frees ALL idle
  * scratch now (whatever running renders own is skipped).  The uploaded scene stays. */
 int trt_scene_trim(trt_scene *s);
 

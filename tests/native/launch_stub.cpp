@@ -68,12 +68,12 @@ hipError_t launch_wavefront(const SceneDev&, const CameraDev& cam, const RenderA
     return stub_render(cam, ra, workspace, wavefront_workspace_bytes(cam.width, ra.rows_local), d_accum, d_counters, stream);
 }
 uint32_t streamed_chunk_spp(uint32_t, uint32_t) { return 4; }
-size_t streamed_workspace_bytes(uint32_t width, uint32_t rows) { return (size_t)width * rows * streamed_chunk_spp(width, rows) * 12u + 256u; }
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t) { return (size_t)width * rows * streamed_chunk_spp(width, rows) * 12u + 256u; }
 const char* streamed_kernel_name(const SceneLayout&, const RenderArgs&) { return "stub"; }
 StreamLaunchPlan streamed_launch_plan(const SceneLayout&, const RenderArgs&, bool) { return StreamLaunchPlan{}; }
 hipError_t launch_streamed(const SceneDev&, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
                            unsigned long long* d_counters, bool, hipStream_t stream) {
-    return stub_render(cam, ra, workspace, streamed_workspace_bytes(cam.width, ra.rows_local), d_accum, d_counters, stream);
+    return stub_render(cam, ra, workspace, streamed_workspace_bytes(cam.width, ra.rows_local, ra.sample_end - ra.sample_begin), d_accum, d_counters, stream);
 }
 hipError_t launch_tonemap_u8(const float*, unsigned long long, float, uint8_t*, hipStream_t) { return hipSuccess; }
 hipError_t launch_sample_batch(const SceneDev&, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out, const RenderArgs&,

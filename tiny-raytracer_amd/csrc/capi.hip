@@ -122,7 +122,8 @@ struct trt_scene {
     std::mutex mu;
     std::condition_variable cv;
     std::unordered_map<int, DeviceCache> dev;     // device ordinal -> cached device resources
-    size_t scratch_cap_bytes = (size_t)8 << 30;   // idle scratch (workspaces + context frames) kept per device; TRT_SCRATCH_CAP_MB
+    size_t scratch_cap_bytes = (size_t)32 << 30;  // idle scratch (workspaces + context frames) kept per device; TRT_SCRATCH_CAP_MB.  One full-size
+                                                  // streamed workspace is up to 16 GB (streamed_chunk_spp): the cap must hold it, or every render re-allocates
 };
 
 namespace {
@@ -458,7 +459,7 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
         // to this render until its last kernel has run (workspace_acquire): concurrent renders of one scene are safe.
         int dev = 0;
         TRT_HIP(hipGetDevice(&dev));
-        const size_t need = wavefront ? wavefront_workspace_bytes(cam->width, rows) : streamed_workspace_bytes(cam->width, rows);
+        const size_t need = wavefront ? wavefront_workspace_bytes(cam->width, rows) : streamed_workspace_bytes(cam->width, rows, ra.sample_end - ra.sample_begin);
         Workspace* ws = nullptr;
         rc = workspace_acquire(s, dev, need, stream, &ws);
         if (rc != TRT_OK) return rc;
@@ -1023,7 +1024,7 @@ int trt_streamed_launch_plan(const trt_scene* s, const trt_camera* cam, const tr
     out->kernel_ray_pool = pl.kernel_pool ? 1u : 0u;
     out->kernel_counting = pl.kernel_stats ? 1u : 0u;
     out->chunk_spp = streamed_chunk_spp(cam->width, rows);
-    out->workspace_bytes = streamed_workspace_bytes(cam->width, rows);
+    out->workspace_bytes = streamed_workspace_bytes(cam->width, rows, ra.sample_end - ra.sample_begin);
     return TRT_OK;
 }
 

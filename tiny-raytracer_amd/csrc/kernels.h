@@ -75,7 +75,7 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
 
 // Streamed backend (streamed.hip): samples are work items; radiances go to an HBM buffer and are folded in order.
 uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows);   // samples per pixel per sample/fold launch pair (bounds the radiance buffer)
-size_t streamed_workspace_bytes(uint32_t width, uint32_t rows);
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples);   // samples = sample_end - sample_begin of the render
 const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra);
 // How launch_streamed runs a scene with these settings (streamed.hip; also what trt_streamed_launch_plan reports).  The
 // kernel's view of its dynamic LDS - scene copy | leaf stack (threads x slots x 8 B) | ray pool (36 B per lane) - is fixed

@@ -17,7 +17,7 @@
 //    frame is bit-identical to the megakernel's and the oracle's whatever lane computed which sample.
 //
 // Cost: 12 B written + 12 B read per sample (a sample is ~7 rays, ~4.6 KB algorithmic), i.e. <1 % extra traffic, and
-// two launches per chunk of samples (sized to a ~4 GB radiance buffer) instead of one.  stream_sample_kernel keeps the
+// two launches per chunk of samples (sized to a radiance buffer of at most 16 GB: streamed_chunk_spp) instead of one.  stream_sample_kernel keeps the
 // primary-ray stock of kernels.hip (items are taken ahead); stream_pool_kernel, used for small LDS scenes, generates the
 // primary rays of a whole wave at once into an LDS pool.
 #include <stdlib.h>
@@ -310,17 +310,26 @@ __global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restric
     out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
 }
 
-// Samples per pixel per sample/fold launch pair: as many as keep the radiance buffer near 4 GB (16..256).
+// Samples per pixel per sample/fold launch pair: as many as keep the radiance buffer within 16 GB (16..256).  Sized for 288 GB of HBM: a
+// launch is a persistent grid that drains a batch queue, and its tail - the last waves finishing their longest paths while the rest of
+// the chip idles - is paid once per launch; the Cornell bench frame went from four 64-spp launches per 256-spp step (4 GB) to one
+// (+1.2 %), random-spheres 1080p from two to one (+2.6 %; profiles/r03_radiance_budget_sweep.txt).  TRT_RADIANCE_GB overrides (1..64).
 uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows) {
     const unsigned long long px = (unsigned long long)width * rows;
-    const unsigned long long fit = px ? (4ull << 30) / (px * 12ull) : 256ull;
+    unsigned long long budget = 16ull << 30;
+    if (const char* e = getenv("TRT_RADIANCE_GB")) { const long g = atol(e); if (g >= 1 && g <= 64) budget = (unsigned long long)g << 30; }
+    const unsigned long long fit = px ? budget / (px * 12ull) : 256ull;
     uint32_t c = 16;
     while (c < 256u && 2ull * c <= fit) c *= 2u;                                  // power of two in 16..256
     while (c > 1u && px * c >= (1ull << 32)) c /= 2u;                             // radiance slots are indexed with 32 bits
     return c;
 }
-size_t streamed_workspace_bytes(uint32_t width, uint32_t rows) {
-    return (size_t)width * rows * streamed_chunk_spp(width, rows) * 3 * sizeof(float) + 256;      // radiance buffer + batch counter
+// Device scratch of one render: [batch counter, 256 bytes] [radiance records: 12 bytes per pixel and sample of a launch].  A render of fewer
+// samples than a full launch holds takes only what it needs.
+constexpr size_t kWorkspaceHeader = 256;
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples) {
+    const uint32_t chunk = streamed_chunk_spp(width, rows);
+    return kWorkspaceHeader + (size_t)width * rows * (samples < chunk ? (samples ? samples : 1u) : chunk) * 3 * sizeof(float);
 }
 
 namespace {
@@ -493,9 +502,11 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
                            unsigned long long* d_counters, bool stats, hipStream_t stream) {
     if (ra_all.rows_local == 0 || cam.width == 0) return hipSuccess;
     const unsigned long long n_pixels = (unsigned long long)ra_all.rows_local * cam.width;
-    float* colors = static_cast<float*>(workspace);
-    const uint32_t chunk = streamed_chunk_spp(cam.width, ra_all.rows_local);
-    uint32_t* batch_counter = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + (size_t)n_pixels * chunk * 3 * sizeof(float));
+    uint32_t* batch_counter = static_cast<uint32_t*>(workspace);                                     // layout: streamed_workspace_bytes
+    float* colors = reinterpret_cast<float*>(static_cast<char*>(workspace) + kWorkspaceHeader);
+    const uint32_t samples_all = ra_all.sample_end - ra_all.sample_begin;
+    const uint32_t chunk_full = streamed_chunk_spp(cam.width, ra_all.rows_local);
+    const uint32_t chunk = samples_all < chunk_full ? (samples_all ? samples_all : 1u) : chunk_full;
     uint32_t tiles_x = (cam.width + 7u) / 8u;
     const uint32_t tiles_y = (ra_all.rows_local + 7u) / 8u;
     uint32_t n_tiles = tiles_x * tiles_y;
