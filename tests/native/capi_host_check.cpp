@@ -112,6 +112,18 @@ static void device_streams(trt_scene* s) {
     hipMemcpy(hc.data(), c, hc.size() * 4, hipMemcpyDeviceToHost);
     CHECK(ha == expected(40, 30, 1, 0, 8) && hb == expected(40, 30, 2, 0, 8) && hc == expected(120, 90, 3, 0, 8), "async frames differ");
     CHECK(launch_stub_corruptions() == 0, "%ld renders shared a workspace", launch_stub_corruptions());
+    // renders enqueued back to back on ONE stream need ONE workspace: stream order serialises them (workspace_acquire, step 1b)
+    CHECK(trt_scene_trim(s) == TRT_OK, "%s", trt_last_error());
+    const long before = hipstub_live_allocations();
+    for (int k = 0; k < 12; k++) {
+        trt_render_params pc = params(3, TRT_BACKEND_STREAMED);
+        CHECK(trt_render_device(s, &big, &pc, c, nullptr, st[2]) == TRT_OK, "%s", trt_last_error());
+    }
+    CHECK(hipstub_live_allocations() - before <= 1, "%ld workspaces for twelve renders on one stream", hipstub_live_allocations() - before);
+    hipStreamSynchronize(st[2]);
+    hipMemcpy(hc.data(), c, hc.size() * 4, hipMemcpyDeviceToHost);
+    CHECK(hc == expected(120, 90, 3, 0, 8), "back-to-back frames differ");
+    CHECK(launch_stub_corruptions() == 0, "%ld renders shared a workspace", launch_stub_corruptions());
     hipFree(a); hipFree(b); hipFree(c);
     for (auto& x : st) hipStreamDestroy(x);
     printf("ok device streams\n");

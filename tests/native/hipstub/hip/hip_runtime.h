@@ -22,6 +22,7 @@ typedef enum {
 typedef enum { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 } hipMemcpyKind;
 typedef struct hipstub_stream* hipStream_t;
 typedef struct hipstub_event* hipEvent_t;
+#define hipStreamPerThread ((hipStream_t)2)       /* the real runtime's per-thread default stream handle: one value, many streams */
 enum { hipEventDisableTiming = 2, hipStreamNonBlocking = 1 };
 
 const char* hipGetErrorString(hipError_t e);

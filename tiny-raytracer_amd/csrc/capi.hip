@@ -94,6 +94,7 @@ struct Workspace {
     void* ptr = nullptr;
     size_t bytes = 0;
     hipEvent_t done = nullptr;
+    hipStream_t last_stream = nullptr;            // the stream `done` was recorded on (valid while recorded)
     bool recorded = false;
     bool busy = false;
 };
@@ -228,6 +229,13 @@ int workspace_acquire(trt_scene* s, int dev, size_t need, hipStream_t stream, Wo
             else if (!regrow) regrow = w;
         }
         enum { USE, REGROW, CREATE, QUEUE, DRAIN } what = USE;
+        // 1b. one whose last render is still in flight ON THIS STREAM: stream order already puts this render behind it - no wait, no second
+        //     buffer.  (Back-to-back renders enqueued on one stream - bench.py's steps, a progressive viewer - otherwise grew the pool to its
+        //     eight workspaces, 16 GB each at full size, and sent the idle ones through the byte cap: a 13 GB hipMalloc + hipFree per render.)
+        //     hipStreamPerThread is one handle for many streams and never matches.
+        if (!pick && stream != hipStreamPerThread) {
+            for (Workspace* w : dc.ws) if (!w->busy && w->recorded && w->last_stream == stream && w->bytes >= need && (!pick || w->bytes < pick->bytes)) pick = w;
+        }
         if (!pick && regrow) { pick = regrow; what = REGROW; }
         // 2. a new one while the pool may grow
         if (!pick && may_grow && dc.ws.size() < kMaxWorkspacesPerDevice) {
@@ -296,6 +304,7 @@ int workspace_release(trt_scene* s, int dev, Workspace* w, hipStream_t stream) {
     {
         std::unique_lock<std::mutex> lock(s->mu);
         w->recorded = recorded;
+        w->last_stream = stream;
         w->busy = false;
         trim_locked(s, lock, s->dev[dev], s->scratch_cap_bytes);
     }
