@@ -85,7 +85,9 @@ int trt_scene_create(const trt_world *w, trt_scene **out);
  * that still run on the device are waited for. */
 void trt_scene_destroy(trt_scene *s);
 /* The scene handle caches device resources per device: the uploaded scene, render scratch ("workspaces": up to 8 per device,
- * e.g. 3.2 GB each at 2048x2048) and, for the blocking entry points, contexts (stream, events, counters, a device frame).
+ * each 12 bytes per pixel and sample of one launch: 3.2 GB for 64 spp at 2048x2048, at most 16 GB - environment TRT_RADIANCE_GB - for
+ * renders of 256 spp and more; renders enqueued back to back on one stream share ONE) and, for the blocking entry points, contexts
+ * (stream, events, counters, a device frame).
  * Idle scratch beyond 32 GiB per device (environment TRT_SCRATCH_CAP_MB) is freed when a render ends; this call frees ALL idle
  * scratch now (whatever running renders own is skipped).  The uploaded scene stays. */
 int trt_scene_trim(trt_scene *s);
