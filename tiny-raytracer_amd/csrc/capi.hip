@@ -109,7 +109,6 @@ struct RenderCtx {
     bool busy = false;
 };
 constexpr size_t kMaxWorkspacesPerDevice = 8;      // beyond that, renders queue behind each other on the device
-constexpr size_t kMaxIdleContextsPerDevice = 16;   // idle contexts beyond that are destroyed at release
 
 struct DeviceCache {
     float4* blob = nullptr;                       // packed scene in HBM
@@ -233,9 +232,14 @@ int workspace_acquire(trt_scene* s, int dev, size_t need, hipStream_t stream, Wo
         //     buffer.  (Back-to-back renders enqueued on one stream - bench.py's steps, a progressive viewer - otherwise grew the pool to its
         //     eight workspaces, 16 GB each at full size, and sent the idle ones through the byte cap: a 13 GB hipMalloc + hipFree per render.)
         //     hipStreamPerThread is one handle for many streams and never matches.
+        //     The wait on `done` is still enqueued (SAME_STREAM below): behind its own stream's work it costs nothing, and it keeps the reuse
+        //     safe should a caller destroy a stream with work pending and get the same handle back for a new one.
+        bool same_stream = false;
         if (!pick && stream != hipStreamPerThread) {
             for (Workspace* w : dc.ws) if (!w->busy && w->recorded && w->last_stream == stream && w->bytes >= need && (!pick || w->bytes < pick->bytes)) pick = w;
+            same_stream = pick != nullptr;
         }
+        if (same_stream) what = QUEUE;
         if (!pick && regrow) { pick = regrow; what = REGROW; }
         // 2. a new one while the pool may grow
         if (!pick && may_grow && dc.ws.size() < kMaxWorkspacesPerDevice) {
@@ -376,24 +380,16 @@ void context_destroy(RenderCtx* c) {                              // idle contex
     delete c;
 }
 
-// The caller has synchronised c->stream (or nothing was enqueued on it).
+// The caller has synchronised c->stream (or nothing was enqueued on it).  The context stays in the pool whatever the pool's size:
+// its stream and events live until trt_scene_destroy (a workspace's `done` event may have been recorded on that stream and is
+// queried by later acquires, so destroying the stream here - round 3 did, beyond 16 idle contexts - brought back the very pattern
+// DESIGN.md's audit of round 2's abort removed).  What a burst of shards leaves behind is bounded by the byte cap: idle contexts'
+// frames are freed largest first by trim_locked; a context without a frame is a stream, two events and 128 bytes of counters.
 void context_release(trt_scene* s, int dev, RenderCtx* c) {
-    std::vector<RenderCtx*> surplus;
-    {
-        std::unique_lock<std::mutex> lock(s->mu);
-        DeviceCache& dc = s->dev[dev];
-        c->busy = false;
-        size_t idle = 0;
-        for (RenderCtx* k : dc.ctx) idle += k->busy ? 0u : 1u;
-        while (idle > kMaxIdleContextsPerDevice) {                // a burst of shards: keep the pool bounded
-            auto it = std::find_if(dc.ctx.begin(), dc.ctx.end(), [](RenderCtx* k) { return !k->busy; });
-            surplus.push_back(*it);
-            dc.ctx.erase(it);
-            idle--;
-        }
-        trim_locked(s, lock, dc, s->scratch_cap_bytes);
-    }
-    for (RenderCtx* k : surplus) context_destroy(k);
+    std::unique_lock<std::mutex> lock(s->mu);
+    DeviceCache& dc = s->dev[dev];
+    c->busy = false;
+    trim_locked(s, lock, dc, s->scratch_cap_bytes);
 }
 
 void to_camera_dev(const trt_camera& c, CameraDev& d) {
@@ -772,18 +768,28 @@ void band_copy_plan(uint32_t width, uint32_t height, uint32_t ndev, uint32_t ran
 }
 
 // Moves one shard's rows between its local buffer and the frame (to_frame: the gather; else: reading the running sums).
+// *per_band (may be null) is set when the rows went band by band instead of as one strided 2-D copy: two devices without peer
+// access, or a runtime that refused the strided copy between two devices (never seen, but that path has only ever run against
+// the simulated runtime of tests/native: on refusal the per-band peer copies - round 2's gather - take over).
 hipError_t copy_bands(const trt_band_copy& pl, char* local, char* frame, bool to_frame, int local_device, int frame_device,
-                      bool peer_ok, hipStream_t stream) {
+                      bool peer_ok, hipStream_t stream, bool* per_band = nullptr) {
     const bool host_frame = frame_device < 0;
     const hipMemcpyKind kind = host_frame ? (to_frame ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice) : hipMemcpyDeviceToDevice;
-    const bool direct = host_frame || frame_device == local_device || peer_ok;
+    const bool cross = !host_frame && frame_device != local_device;
+    bool direct = host_frame || !cross || peer_ok;
     if (pl.full_bands) {
         if (direct) {
             hipError_t e = to_frame
                 ? hipMemcpy2DAsync(frame + pl.frame_offset, pl.frame_pitch, local, pl.local_pitch, pl.band_bytes, pl.full_bands, kind, stream)
                 : hipMemcpy2DAsync(local, pl.local_pitch, frame + pl.frame_offset, pl.frame_pitch, pl.band_bytes, pl.full_bands, kind, stream);
-            if (e != hipSuccess) return e;
-        } else {                                                  // no peer access: the runtime stages each band through the host
+            if (e != hipSuccess) {
+                if (!cross) return e;
+                (void)hipGetLastError();
+                direct = false;                                   // the strided cross-device copy was refused: band by band
+            }
+        }
+        if (!direct) {                                            // no peer access (the runtime stages each band through the host), or the fallback
+            if (per_band) *per_band = true;
             for (uint32_t k = 0; k < pl.full_bands; k++) {
                 char* l = local + (uint64_t)k * pl.local_pitch;
                 char* f = frame + pl.frame_offset + (uint64_t)k * pl.frame_pitch;
@@ -797,6 +803,7 @@ hipError_t copy_bands(const trt_band_copy& pl, char* local, char* frame, bool to
         char* l = local + pl.tail_local_offset;
         char* f = frame + pl.tail_frame_offset;
         if (direct) return to_frame ? hipMemcpyAsync(f, l, pl.tail_bytes, kind, stream) : hipMemcpyAsync(l, f, pl.tail_bytes, kind, stream);
+        if (per_band) *per_band = true;
         return to_frame ? hipMemcpyPeerAsync(f, frame_device, l, local_device, pl.tail_bytes, stream)
                         : hipMemcpyPeerAsync(l, local_device, f, frame_device, pl.tail_bytes, stream);
     }
