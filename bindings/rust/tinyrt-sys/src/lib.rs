@@ -1,11 +1,11 @@
-//! Raw declarations of `include/tinyrt.h` (ABI version 2).  Field order, scalar types and function parameter lists are
+//! Raw declarations of `include/tinyrt.h` (ABI version 3).  Field order, scalar types and function parameter lists are
 //! checked against the header by tests/test_rust_bindings.py; the crate itself has never been compiled (no Rust
 //! toolchain in the build image).
 #![allow(non_camel_case_types)]
 
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const TRT_ABI_VERSION: u32 = 2;
+pub const TRT_ABI_VERSION: u32 = 3;
 
 // enum trt_status
 pub const TRT_OK: c_int = 0;
@@ -94,8 +94,44 @@ pub struct trt_camera {
     pub height: u32,
 }
 
+/// Placement of a compiled scene (every value renders the same frames); fill with `trt_scene_options_default`.
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default, PartialEq)]
+pub struct trt_scene_options {
+    pub cull_prune: f32,
+    pub flat_walk: i32,
+    pub compact_nodes: i32,
+    pub top_nodes: u32,
+    pub scratch_cap_bytes: u64,
+    pub reserved: [u32; 6],
+}
+
+/// Scheduling of a render (every value renders the same frame); fill with `trt_tuning_default`.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default, PartialEq)]
+pub struct trt_tuning {
+    pub stream_waves_per_simd: u32,
+    pub stream_big_threads: u32,
+    pub stream_batch_spp: u32,
+    pub radiance_gb: u32,
+    pub leaf_slots: u32,
+    pub lds_leaf_stack: u32,
+    pub ray_pool: u32,
+    pub stragglers: u32,
+    pub lds_stragglers: u32,
+    pub dual_walk: u32,
+    pub runtime_walk: u32,
+    pub xcd_remap: u32,
+    pub mega_waves_per_simd: u32,
+    pub mega_threads: u32,
+    pub mega_global_waves8: u32,
+    pub wf_waves_per_simd: u32,
+    pub wf_serve_min: u32,
+    pub reserved: [u32; 7],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, PartialEq)]
 pub struct trt_render_params {
     pub samples_per_pixel: u32,
     pub max_bounces: u32,
@@ -110,6 +146,13 @@ pub struct trt_render_params {
     pub band_offset: u32,
     pub rows_local: u32,
     pub collect_stats: u32,
+    pub tuning: *const trt_tuning,
+}
+impl Default for trt_render_params {
+    fn default() -> Self {
+        // all-zero: whole image, all samples, the library's default tuning (null)
+        unsafe { std::mem::zeroed() }
+    }
 }
 
 #[repr(C)]
@@ -149,6 +192,7 @@ pub struct trt_launch_plan {
     pub kernel_ray_pool: u32,
     pub kernel_counting: u32,
     pub chunk_spp: u32,
+    pub dual_walk: u32,
     pub workspace_bytes: u64,
 }
 
@@ -164,6 +208,7 @@ pub struct trt_stats {
     pub shades: u64,
     pub kernel_ms: f64,
     pub wave_trips: [u64; 4],
+    pub gather_per_band: u64,
 }
 
 /// Opaque handles (owned by the library).
@@ -187,6 +232,9 @@ extern "C" {
     pub fn trt_world_num_materials(w: *const trt_world) -> c_int;
 
     pub fn trt_scene_create(w: *const trt_world, out: *mut *mut trt_scene) -> c_int;
+    pub fn trt_scene_options_default(out: *mut trt_scene_options);
+    pub fn trt_scene_create_ex(w: *const trt_world, options: *const trt_scene_options, out: *mut *mut trt_scene) -> c_int;
+    pub fn trt_tuning_default(out: *mut trt_tuning);
     pub fn trt_scene_destroy(s: *mut trt_scene);
     pub fn trt_scene_trim(s: *mut trt_scene) -> c_int;
     pub fn trt_scene_get_info(s: *const trt_scene, out: *mut trt_scene_info) -> c_int;

@@ -275,6 +275,9 @@ pub struct Renderer {
     background_color: Vec3,
     pub seed: u32,    // trt-rng v1 seed (the reference has no seed API)
     pub backend: u32, // one of the TRT_BACKEND constants of tinyrt-sys
+    /// Scheduling knobs (`sys::trt_tuning`, from `Renderer::default_tuning()`); `None` = the library defaults.  Scheduling only:
+    /// whatever the values, the frame is the same.
+    pub tuning: Option<sys::trt_tuning>,
 }
 
 impl Renderer {
@@ -288,7 +291,15 @@ impl Renderer {
             background_color: background_color.unwrap_or_else(Vec3::zero), // renderer.rs:33
             seed: 1,
             backend: sys::TRT_BACKEND_AUTO,
+            tuning: None,
         }
+    }
+
+    /// The library's default tuning (built-in values; TRT_* environment variables override them once, when the library is loaded).
+    pub fn default_tuning() -> sys::trt_tuning {
+        let mut t = sys::trt_tuning::default();
+        unsafe { sys::trt_tuning_default(&mut t) };
+        t
     }
 
     /// Renderer::render (renderer.rs:37-79), synchronous; wrap in `tokio::task::spawn_blocking` for a JoinHandle<Image>.
@@ -301,6 +312,7 @@ impl Renderer {
             background: self.background_color.raw(),
             seed: self.seed,
             backend: self.backend,
+            tuning: self.tuning.as_ref().map_or(ptr::null(), |t| t as *const sys::trt_tuning),
             ..Default::default()
         };
         let mut data = vec![0.0 as Float; width * height * 3];
@@ -319,6 +331,7 @@ impl Renderer {
             background: self.background_color.raw(),
             seed: self.seed,
             backend: self.backend,
+            tuning: self.tuning.as_ref().map_or(ptr::null(), |t| t as *const sys::trt_tuning),
             ..Default::default()
         };
         let mut data = vec![0.0 as Float; width * height * 3];

@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define TRT_ABI_VERSION 2   /* 2 (round 3): + trt_scene_trim, trt_streamed_launch_plan, trt_band_copy_plan */
+#define TRT_ABI_VERSION 3   /* 2 (round 3): + trt_scene_trim, trt_streamed_launch_plan, trt_band_copy_plan
+                             * 3 (round 4): tuning moved out of the process environment: trt_tuning (trt_render_params.tuning),
+                             *              trt_scene_options + trt_scene_create_ex; trt_stats.gather_per_band */
 
 enum trt_status {
     TRT_OK = 0,
@@ -80,15 +82,28 @@ int trt_world_num_materials(const trt_world *w);
  * pre-order skip-link array, packing into 16-byte planes).  Device upload happens lazily
  * on first render, so a scene can be compiled and inspected on a machine without a GPU. */
 typedef struct trt_scene trt_scene;
-int trt_scene_create(const trt_world *w, trt_scene **out);
+int trt_scene_create(const trt_world *w, trt_scene **out);                          /* = trt_scene_create_ex(w, NULL, out) */
+/* How a scene is compiled and how much idle device scratch its handle keeps.  PLACEMENT ONLY: every value renders the same
+ * frames, bit for bit (the reference has one BVH layout and no such choice: bvh.rs:42-84).  Fill with
+ * trt_scene_options_default() and change fields; NULL = the defaults. */
+typedef struct {
+    float cull_prune;             /* culling tree: an inner node whose box is >= this share of its nearest kept ancestor's is dropped (0.5) */
+    int32_t flat_walk;            /* lock-step leaf list instead of a tree walk: -1 = for at most 32 primitives (default), 0 never, 1 always */
+    int32_t compact_nodes;        /* 16-byte f16 culling nodes: -1 = for scenes too large for LDS (default), 0 never, 1 always */
+    uint32_t top_nodes;           /* culling-tree nodes (whole levels) placed first and LDS-cached by large scenes; 0 = off (default: measured slower) */
+    uint64_t scratch_cap_bytes;   /* idle scratch (workspaces + context frames) kept per device between renders; default 32 GiB */
+    uint32_t reserved[6];         /* zero */
+} trt_scene_options;
+void trt_scene_options_default(trt_scene_options *out);
+int trt_scene_create_ex(const trt_world *w, const trt_scene_options *options, trt_scene **out);
 /* Must not run while another host thread is inside a render call on this scene; renders enqueued with trt_render_device
  * that still run on the device are waited for. */
 void trt_scene_destroy(trt_scene *s);
 /* The scene handle caches device resources per device: the uploaded scene, render scratch ("workspaces": up to 8 per device,
- * each 12 bytes per pixel and sample of one launch: 3.2 GB for 64 spp at 2048x2048, at most 16 GB - environment TRT_RADIANCE_GB - for
+ * each 12 bytes per pixel and sample of one launch: 3.2 GB for 64 spp at 2048x2048, at most 16 GB - trt_tuning.radiance_gb - for
  * renders of 256 spp and more; renders enqueued back to back on one stream share ONE) and, for the blocking entry points, contexts
  * (stream, events, counters, a device frame).
- * Idle scratch beyond 32 GiB per device (environment TRT_SCRATCH_CAP_MB) is freed when a render ends; this call frees ALL idle
+ * Idle scratch beyond 32 GiB per device (trt_scene_options.scratch_cap_bytes) is freed when a render ends; this call frees ALL idle
  * scratch now (whatever running renders own is skipped).  The uploaded scene stays. */
 int trt_scene_trim(trt_scene *s);
 
@@ -131,6 +146,35 @@ enum trt_backend {
     TRT_BACKEND_AUTO = 2,         /* the fastest measured backend (currently TRT_BACKEND_STREAMED for every scene) */
     TRT_BACKEND_STREAMED = 3      /* samples as work items pulled by persistent waves; radiances folded per pixel in sample order */
 };
+/* Scheduling of a render.  EVERY field is scheduling or placement only: any value renders the same frame, bit for bit, with the
+ * same ray count (each is covered by a bit-equality test).  The reference configures a render through constructor arguments
+ * (renderer.rs:21-35), never through the environment; so does this library: fill with trt_tuning_default() - the built-in
+ * defaults, overridden ONCE, when the library is loaded, by the TRT_* environment variables named below (for sweeps from a shell) -
+ * change fields, and hand it over in trt_render_params.tuning (NULL = trt_tuning_default()).  Nothing on the launch path reads
+ * the environment; two threads may render one scene with different tunings at the same time. */
+typedef struct {
+    uint32_t stream_waves_per_simd;   /* streamed backend: waves per SIMD grid and launch bound are sized for; 0 = by scene (6 for scenes
+                                         in LDS, 8 for scenes in global memory); 5..8                      TRT_STREAM_MINW */
+    uint32_t stream_big_threads;      /* lanes per workgroup for LDS scene copies above 20 KB: 0 = auto, 512, 768   TRT_BIG_THREADS */
+    uint32_t stream_batch_spp;        /* samples per pixel in one work batch of a wave (8)                  TRT_STREAM_BATCH_SPP */
+    uint32_t radiance_gb;             /* radiance records of one streamed launch, GiB (16; 1..64)           TRT_RADIANCE_GB */
+    uint32_t leaf_slots;              /* postponed leaves per lane and walk; 0 = by launch plan             TRT_LEAF_SLOTS */
+    uint32_t lds_leaf_stack;          /* where they live: 0 registers, 1 LDS where it costs no occupancy (default), 2 LDS always   TRT_LDS_LEAF_STACK */
+    uint32_t ray_pool;                /* 1 (default): per-wave LDS pool of primary rays where it fits; 0: one ray in stock per lane   TRT_RAY_POOL */
+    uint32_t stragglers;              /* 16-byte-node walk: lanes that may carry an unfinished walk into the next round (8; 0 = none)   TRT_STRAGGLERS */
+    uint32_t lds_stragglers;          /* the same for the LDS tree walk (8)                                 TRT_LDS_STRAGGLERS */
+    uint32_t dual_walk;               /* scenes in global memory: two paths per lane, two node loads in flight per wave   TRT_DUAL_WALK */
+    uint32_t runtime_walk;            /* 1: the kernels that choose the walk at run time instead of the specialised ones (0)   TRT_RUNTIME_WALK */
+    uint32_t xcd_remap;               /* 1: contiguous image regions per XCD (0: measured 2x slower)        TRT_XCD_REMAP */
+    uint32_t mega_waves_per_simd;     /* megakernel backend: 0 = default (7)                                TRT_MINW */
+    uint32_t mega_threads;            /* megakernel: lanes per workgroup, 0 = auto, 256, 512                TRT_MEGA_THREADS */
+    uint32_t mega_global_waves8;      /* megakernel on scenes in global memory: 8 waves per SIMD (0)        TRT_MINW8 */
+    uint32_t wf_waves_per_simd;       /* wavefront backend: 0 = default                                     TRT_WF_MINW */
+    uint32_t wf_serve_min;            /* wavefront backend: lanes that must wait before a refill; 0 = default (24)   TRT_WF_SERVE_MIN */
+    uint32_t reserved[7];             /* zero */
+} trt_tuning;
+void trt_tuning_default(trt_tuning *out);
+
 typedef struct {
     uint32_t samples_per_pixel;   /* Renderer::samples_per_pixel: fixes the 1/spp scale (imager.rs:35) */
     uint32_t max_bounces;         /* Renderer::max_bounces */
@@ -147,6 +191,7 @@ typedef struct {
     uint32_t collect_stats;       /* 0: count samples and rays only.  1: counting kernel variant walking the REFERENCE tree:
                                      node/primitive test counts equal the CPU path's (SURVEY §8d's algorithmic bytes).
                                      2: counting variant walking the culling tree: the box tests actually performed. */
+    const trt_tuning *tuning;     /* scheduling knobs (see trt_tuning); NULL = trt_tuning_default().  Read during the call only. */
 } trt_render_params;
 
 typedef struct {
@@ -160,6 +205,8 @@ typedef struct {
     double kernel_ms;             /* device time of the launch(es), HIP events on the launch stream (host-buffer calls only) */
     uint64_t wave_trips[4];       /* diagnostics, collect_stats only: per-wave loop trips (bounce rounds, box-test steps,
                                      leaf phases, ray generations); lane-level counts / (64 x these) = SIMD utilisation */
+    uint64_t gather_per_band;     /* trt_render_multi*: shards whose rows were gathered band by band instead of by one strided 2-D copy
+                                     (no peer access between two devices, or the runtime refused the strided peer copy); else 0 */
 } trt_stats;
 
 /* Renderer::render(camera, world) (renderer.rs:37-79), synchronous.  `accum` is a HOST buffer
@@ -238,13 +285,15 @@ typedef struct {
     uint32_t specialised;             /* 1: a kernel with the walk fixed at compile time */
     uint32_t has_kernel;              /* 0 would be a bug: no instantiation for the plan (the launch then fails, it never falls back) */
     uint32_t kernel_waves_per_simd, kernel_threads, kernel_walk /* 0 = chosen at run time */, kernel_ray_pool, kernel_counting;
-    uint32_t chunk_spp;               /* = trt_streamed_chunk_spp(width, rows) */
+    uint32_t chunk_spp;               /* samples per pixel per launch under p->tuning (= trt_streamed_chunk_spp(width, rows) for the default tuning) */
+    uint32_t dual_walk;               /* 1: two paths per lane (two leaf stacks per lane in LDS) */
     uint64_t workspace_bytes;         /* device scratch one render of this size takes from the scene's pool */
 } trt_launch_plan;
 int trt_streamed_launch_plan(const trt_scene *s, const trt_camera *cam, const trt_render_params *p, trt_launch_plan *out);
 
-/* Samples per pixel the streamed backend traces per kernel launch for an image of this size (it splits longer sample
- * ranges into such chunks; one chunk = one `trt::stream_sample_kernel` launch + one fold launch). */
+/* Samples per pixel the streamed backend traces per kernel launch for an image of this size under the default tuning (it splits
+ * longer sample ranges into such chunks; one chunk = one tracing-kernel launch + one fold launch).  For another tuning:
+ * trt_streamed_launch_plan's chunk_spp. */
 uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows);
 
 /* Measurement aid: between _begin and _end every launch of a render's dominant kernel (streamed backend: the sample

@@ -89,8 +89,15 @@ public:
     }
     // World::get_bvh (world.rs:43-45): the reference-order BVH, packed for the GPU; cached until the world changes
     trt_scene* get_bvh() {
-        if (!scene_) check(trt_scene_create(w_, &scene_));
+        if (!scene_) check(trt_scene_create_ex(w_, has_options_ ? &options_ : nullptr, &scene_));
         return scene_;
+    }
+    // How the scene is compiled (trt_scene_options: placement only, every value renders the same frames).  Starts from the library
+    // defaults; takes effect at the next get_bvh().
+    trt_scene_options& scene_options() {
+        if (!has_options_) { trt_scene_options_default(&options_); has_options_ = true; }
+        invalidate();
+        return options_;
     }
     int num_geometries() const { return trt_world_num_geometries(w_); }
     // Frees the device scratch (render workspaces, frame buffers) the compiled scene caches between renders (trt_scene_trim).
@@ -100,6 +107,8 @@ private:
     void invalidate() { if (scene_) { trt_scene_destroy(scene_); scene_ = nullptr; } }
     trt_world* w_ = nullptr;
     trt_scene* scene_ = nullptr;
+    trt_scene_options options_{};
+    bool has_options_ = false;
 };
 
 class Camera {
@@ -226,9 +235,21 @@ public:
         return img;
     }
     trt_render_params& params() { return params_; }
+    // Scheduling knobs of this renderer (trt_tuning: every value renders the same frame).  Starts from the library defaults.
+    trt_tuning& tuning() {
+        if (!params_.tuning) { trt_tuning_default(&tuning_); params_.tuning = &tuning_; }
+        return tuning_;
+    }
+    Renderer(const Renderer& o) : params_(o.params_), tuning_(o.tuning_) { if (o.params_.tuning) params_.tuning = &tuning_; }
+    Renderer& operator=(const Renderer& o) {
+        params_ = o.params_; tuning_ = o.tuning_;
+        if (o.params_.tuning) params_.tuning = &tuning_;
+        return *this;
+    }
 
 private:
     trt_render_params params_;
+    trt_tuning tuning_{};
 };
 
 }  // namespace tinyrt

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <atomic>
 #include <string>
 #include <thread>
@@ -16,6 +17,7 @@
 
 extern "C" long launch_stub_corruptions(void);
 extern "C" long launch_stub_launches(void);
+extern "C" long launch_stub_short_launches(void);
 namespace trt { float stub_pattern(uint32_t y, uint32_t x, int c, uint32_t seed_key, uint32_t s0, uint32_t s1); }
 
 static int g_failures = 0;
@@ -41,14 +43,14 @@ static std::vector<float> expected(uint32_t w, uint32_t h, uint32_t seed, uint32
     return f;
 }
 
-static trt_scene* make_scene() {
+static trt_scene* make_scene(const trt_scene_options* opt = nullptr) {
     trt_world* w = nullptr;
     trt_world_create(&w);
     trt_material m{TRT_LAMBERTIAN, {0.5f, 0.5f, 0.5f}, 0.0f};
     trt_world_add_material(w, "m", &m);
     for (int i = 0; i < 5; i++) trt_world_add_sphere(w, trt_vec3{(float)i, 0.0f, -3.0f}, 0.4f, 0);
     trt_scene* s = nullptr;
-    if (trt_scene_create(w, &s) != TRT_OK) { printf("scene: %s\n", trt_last_error()); exit(2); }
+    if (trt_scene_create_ex(w, opt, &s) != TRT_OK) { printf("scene: %s\n", trt_last_error()); exit(2); }
     trt_world_destroy(w);
     return s;
 }
@@ -59,7 +61,7 @@ static trt_camera make_camera(uint32_t w, uint32_t h) {
 }
 static trt_render_params params(uint32_t seed, uint32_t backend, uint32_t s0 = 0, uint32_t s1 = 0, uint32_t acc = 0) {
     trt_render_params p;
-    memset(&p, 0, sizeof(p));
+    memset(&p, 0, sizeof(p));                                              // tuning = NULL: the library defaults
     p.samples_per_pixel = 8; p.max_bounces = 4; p.seed = seed; p.backend = backend; p.sample_begin = s0; p.sample_end = s1; p.accumulate = acc;
     return p;
 }
@@ -166,6 +168,106 @@ static void multi(trt_scene* s) {
     printf("ok multi: %ld live streams, %ld live allocations\n", hipstub_live_streams(), hipstub_live_allocations());
 }
 
+// more shards on ONE device than round 3's idle-context limit (16): no stream or event is destroyed while the scene lives (ADVICE r3:
+// context_release used to destroy surplus contexts, whose streams workspace events had been recorded on), later calls reuse the pool
+static void many_shards_on_one_device(trt_scene* s) {
+    std::vector<int> devs(40, 1);
+    const uint32_t w = 24, h = 40 * 16 + 5;
+    trt_camera cam = make_camera(w, h);
+    std::vector<float> frame((size_t)w * h * 3);
+    const long errors_before = hipstub_errors();
+    long streams_after_first = 0;
+    for (int rep = 0; rep < 3; rep++) {
+        trt_render_params p = params(21 + rep, TRT_BACKEND_AUTO);
+        trt_stats st;
+        CHECK(trt_render_multi(s, &cam, &p, devs.data(), 40, frame.data(), &st) == TRT_OK, "%s", trt_last_error());
+        CHECK(frame == expected(w, h, 21 + rep, 0, 8), "40 shards on one device, rep %d", rep);
+        CHECK(st.gather_per_band == 0, "host frame gathered band by band");
+        if (rep == 0) streams_after_first = hipstub_live_streams();
+        else CHECK(hipstub_live_streams() <= streams_after_first + 8, "the context pool keeps growing: %ld -> %ld streams", streams_after_first, hipstub_live_streams());
+    }
+    CHECK(hipstub_errors() == errors_before, "%ld uses of a destroyed stream / event", hipstub_errors() - errors_before);
+    CHECK(launch_stub_corruptions() == 0, "%ld renders shared a workspace", launch_stub_corruptions());
+    printf("ok 40 shards on one device: %ld live streams\n", hipstub_live_streams());
+}
+
+// What the gather relies on, read off the order in which the simulated runtime EXECUTED things: on every shard's stream the running sums
+// come in (progressive pass) before the kernel, the kernel runs before the shard's rows leave, the rows of different shards never overlap
+// in the frame, together they cover it exactly once, and nothing touches the frame after the call has returned - with peer access (one
+// strided 2-D copy per shard) and without (band by band, reported in trt_stats.gather_per_band).
+static void gather_ordering(trt_scene* s) {
+    const int devs[4] = {0, 1, 2, 3};
+    const uint32_t w = 20, h = 16 * 9 + 7;                                   // ten bands, the last one ragged
+    trt_camera cam = make_camera(w, h);
+    const size_t frame_bytes = (size_t)w * h * 12;
+    for (const char* peer : {"1", "0"}) {
+        setenv("HIPSTUB_PEER", peer, 1);
+        hipSetDevice(0);
+        float* d = nullptr;
+        hipMalloc((void**)&d, frame_bytes);
+        for (uint32_t acc = 0; acc < 2; acc++) {
+            trt_render_params p = params(31, TRT_BACKEND_AUTO, 0, 8, acc);
+            trt_stats st;
+            hipstub_oplog_start();
+            CHECK(trt_render_multi_device(s, &cam, &p, devs, 4, d, &st) == TRT_OK, "%s", trt_last_error());
+            std::vector<hipstub_op> log = hipstub_oplog_stop();
+            const char* lo = reinterpret_cast<const char*>(d);
+            auto in_frame = [&](const void* q) { return q >= (const void*)lo && q < (const void*)(lo + frame_bytes); };
+            std::vector<int> written(frame_bytes / 4, 0);
+            std::vector<hipStream_t> streams;
+            for (const hipstub_op& op : log) if (std::find(streams.begin(), streams.end(), op.stream) == streams.end()) streams.push_back(op.stream);
+            int kernels = 0;
+            for (hipStream_t sm : streams) {
+                int phase = 0;                                               // 0 before the kernel, 1 after it
+                bool saw_read = false, saw_write = false;
+                for (const hipstub_op& op : log) {
+                    if (op.stream != sm) continue;
+                    if (!strcmp(op.kind, "kernel")) { CHECK(phase == 0, "two kernels on one shard stream"); phase = 1; kernels++; continue; }
+                    if (in_frame(op.src)) { CHECK(phase == 0, "peer %s acc %u: running sums read AFTER the kernel", peer, acc); saw_read = true; }
+                    if (in_frame(op.dst)) {
+                        CHECK(phase == 1, "peer %s acc %u: rows written to the frame BEFORE the kernel", peer, acc);
+                        saw_write = true;
+                        for (size_t r = 0; r < op.height; r++)
+                            for (size_t b = 0; b < op.width; b += 4) written[((const char*)op.dst - lo + r * op.dpitch + b) / 4]++;
+                    }
+                }
+                if (phase == 1) CHECK(saw_write && saw_read == (acc == 1), "peer %s acc %u: a shard that rendered did not gather (or read sums it should not)", peer, acc);
+            }
+            CHECK(kernels == 4, "%d shard kernels", kernels);
+            bool once = true;
+            for (int c : written) once = once && c == 1;
+            CHECK(once, "peer %s acc %u: the shards' rows do not tile the frame exactly once", peer, acc);
+            CHECK(st.gather_per_band == (strcmp(peer, "0") ? 0u : 3u), "peer %s: gather_per_band %llu", peer, (unsigned long long)st.gather_per_band);
+            // the call has returned: nothing is still queued that touches the frame
+            hipstub_oplog_start();
+            std::vector<float> back(frame_bytes / 4);
+            hipMemcpy(back.data(), d, frame_bytes, hipMemcpyDeviceToHost);
+            log = hipstub_oplog_stop();
+            for (const hipstub_op& op : log) CHECK(!in_frame(op.dst), "a write to the frame ran after trt_render_multi_device returned");
+            CHECK(back == expected(w, h, 31, 0, 8, acc ? 2 : 1), "peer %s acc %u frame", peer, acc);
+        }
+        hipFree(d);
+    }
+    // the runtime refuses the strided copy between two devices: the per-band peer copies take over, and the stats say so
+    setenv("HIPSTUB_PEER", "1", 1);
+    {
+        hipSetDevice(0);
+        float* d = nullptr;
+        hipMalloc((void**)&d, frame_bytes);
+        trt_render_params p = params(32, TRT_BACKEND_AUTO);
+        trt_stats st;
+        setenv("HIPSTUB_REFUSE_CROSS_2D", "1", 1);
+        CHECK(trt_render_multi_device(s, &cam, &p, devs, 4, d, &st) == TRT_OK, "%s", trt_last_error());
+        unsetenv("HIPSTUB_REFUSE_CROSS_2D");
+        std::vector<float> back(frame_bytes / 4);
+        hipMemcpy(back.data(), d, frame_bytes, hipMemcpyDeviceToHost);
+        CHECK(back == expected(w, h, 32, 0, 8), "frame after the refused strided copy");
+        CHECK(st.gather_per_band == 3, "fallback not reported: %llu", (unsigned long long)st.gather_per_band);
+        hipFree(d);
+    }
+    printf("ok gather ordering\n");
+}
+
 // timing brackets with several rendering threads and a multi-device render in flight: pairs never mix
 static void timing(trt_scene* s) {
     CHECK(trt_kernel_timing_begin() == TRT_OK, "begin");
@@ -192,9 +294,10 @@ static void timing(trt_scene* s) {
 
 // the byte cap: idle scratch is freed when renders end; trim frees the rest
 static void cap_and_trim() {
-    setenv("TRT_SCRATCH_CAP_MB", "1", 1);
-    trt_scene* s = make_scene();
-    unsetenv("TRT_SCRATCH_CAP_MB");
+    trt_scene_options opt;
+    trt_scene_options_default(&opt);
+    opt.scratch_cap_bytes = 1u << 20;
+    trt_scene* s = make_scene(&opt);
     const size_t base = hipstub_live_bytes();
     trt_camera cam = make_camera(256, 200);                                  // streamed workspace 2.4 MB, frame 0.6 MB
     std::vector<std::thread> th;
@@ -258,11 +361,28 @@ static void failure_injection() {
             std::vector<float> f(128 * 100 * 3);
             trt_render_params p = params(t, TRT_BACKEND_STREAMED);
             int rc = trt_render(s, &cam, &p, f.data(), nullptr);
-            if (rc == TRT_OK && f == expected(128, 100, t, 0, 8)) ok++; else if (rc == TRT_ERR_HIP) oom++; else { printf("FAIL oom render rc %d\n", rc); g_failures++; }
+            if (rc == TRT_OK && f == expected(128, 100, t, 0, 8)) ok++; else if (rc == TRT_ERR_HIP || rc == TRT_ERR_OOM) oom++; else { printf("FAIL oom render rc %d\n", rc); g_failures++; }
         });
         for (auto& t : th) t.join();
         unsetenv("HIPSTUB_HBM_BYTES");
         CHECK(ok >= 1 && ok + oom == 6, "ok %d oom %d", ok.load(), oom.load());
+        trt_scene_destroy(s);
+    }
+    // a FIRST render that cannot have its full-size scratch (torch, or another scene's cached scratch, holds the HBM): it asks for
+    // half the samples per launch, and half again, instead of failing; the frame is the same
+    {
+        trt_scene* s = make_scene();
+        trt_camera cam = make_camera(128, 100);                              // full-size workspace: 128 x 100 x 4 spp x 12 B = 614 KB; frame 154 KB
+        char cap[32];
+        snprintf(cap, sizeof cap, "%zu", hipstub_live_bytes() + 154u * 1024u + 400u * 1024u);      // room for the frame and two thirds of the workspace
+        setenv("HIPSTUB_HBM_BYTES", cap, 1);
+        const long before = launch_stub_short_launches();
+        std::vector<float> f(128 * 100 * 3);
+        trt_render_params p = params(11, TRT_BACKEND_STREAMED);
+        const int rc = trt_render(s, &cam, &p, f.data(), nullptr);
+        unsetenv("HIPSTUB_HBM_BYTES");
+        CHECK(rc == TRT_OK && f == expected(128, 100, 11, 0, 8), "render with HBM short: rc %d %s", rc, trt_last_error());
+        CHECK(launch_stub_short_launches() > before, "the render was not granted a smaller workspace");
         trt_scene_destroy(s);
     }
     printf("ok failure injection (%d failed calls recovered from)\n", failed_calls);
@@ -275,6 +395,8 @@ int main(int argc, char** argv) {
     concurrent_renders(s);
     device_streams(s);
     multi(s);
+    many_shards_on_one_device(s);
+    gather_ordering(s);
     timing(s);
     trt_scene_destroy(s);
     CHECK(hipstub_live_allocations() == (long)base_allocs && hipstub_live_streams() == 0 && hipstub_live_events() == 0,

@@ -61,4 +61,19 @@ long hipstub_live_events(void);
 size_t hipstub_live_bytes(void);
 size_t hipstub_peak_bytes(void);
 void hipstub_reset_peak(void);
+// Operation log (ordering tests): while on, every copy / memset the stub EXECUTES - and whatever a launcher stub reports through
+// hipstub_log - is appended in execution order with the stream it ran on.
+#include <vector>
+struct hipstub_op {
+    unsigned long long seq;
+    hipStream_t stream;
+    int device;                    // the device the stream belongs to
+    const char* kind;              // "copy", "copy2d", "peer", "memset", or what hipstub_log was given ("kernel")
+    const void* dst;
+    const void* src;
+    size_t width, height, dpitch;  // bytes per row, rows, destination pitch (1-D operations: height 1)
+};
+void hipstub_oplog_start(void);
+std::vector<hipstub_op> hipstub_oplog_stop(void);
+void hipstub_log(const char* kind, const void* dst, const void* src, size_t width, size_t height, size_t dpitch);    // from inside a stream task
 long hipstub_errors(void);                                            // protocol violations the stub itself saw (use of a destroyed stream / event, ...)

@@ -24,6 +24,7 @@ struct hipstub_event {
     int device = 0;
 };
 
+static void t_running_on_set(struct hipstub_stream* s);
 struct hipstub_stream {
     std::mutex mu;
     std::condition_variable cv;
@@ -40,6 +41,7 @@ struct hipstub_stream {
             q.pop_front();
             running = true;
             lock.unlock();
+            t_running_on_set(this);
             t();
             lock.lock();
             running = false;
@@ -58,12 +60,17 @@ std::shared_mutex g_life;                                 // shared: somebody wa
 std::set<hipstub_stream*> g_streams;
 std::set<hipstub_event*> g_events;
 std::map<void*, size_t> g_allocs;
+std::map<void*, int> g_alloc_dev;                          // allocation -> device it was made on
 std::map<int, hipstub_stream*> g_default_stream;
 size_t g_live_bytes = 0, g_peak_bytes = 0;
 std::map<std::string, long> g_fail;
 std::atomic<long> g_errors{0};
 thread_local int t_device = 0;
 thread_local hipError_t t_last = hipSuccess;
+thread_local hipstub_stream* t_running_on = nullptr;      // the stream whose worker thread this is
+std::mutex g_log_mu;
+bool g_log_on = false;
+std::vector<hipstub_op> g_log;
 
 int device_count() { const char* e = getenv("HIPSTUB_DEVICES"); int n = e ? atoi(e) : 2; return n; }
 bool inject(const char* api) {
@@ -106,6 +113,14 @@ std::vector<hipstub_stream*> streams_of(int dev) {
 }
 }  // namespace
 
+static void t_running_on_set(hipstub_stream* s) { t_running_on = s; }
+void hipstub_oplog_start(void) { std::lock_guard<std::mutex> lock(g_log_mu); g_log.clear(); g_log_on = true; }
+std::vector<hipstub_op> hipstub_oplog_stop(void) { std::lock_guard<std::mutex> lock(g_log_mu); g_log_on = false; return std::move(g_log); }
+void hipstub_log(const char* kind, const void* dst, const void* src, size_t width, size_t height, size_t dpitch) {
+    std::lock_guard<std::mutex> lock(g_log_mu);
+    if (!g_log_on) return;
+    g_log.push_back(hipstub_op{(unsigned long long)g_log.size(), t_running_on, t_running_on ? t_running_on->device : -1, kind, dst, src, width, height, dpitch});
+}
 void hipstub_enqueue(hipStream_t s, std::function<void()> task) {
     hipstub_stream* st = resolve(s);
     if (!st) return;
@@ -146,6 +161,7 @@ hipError_t hipMalloc(void** p, size_t bytes) {
     if (!q) { *p = nullptr; return ret(hipErrorOutOfMemory); }
     memset(q, 0xA5, bytes);                                    // device memory is not zeroed
     g_allocs[q] = bytes;
+    g_alloc_dev[q] = t_device;
     g_live_bytes += bytes;
     if (g_live_bytes > g_peak_bytes) g_peak_bytes = g_live_bytes;
     *p = q;
@@ -162,12 +178,13 @@ hipError_t hipFree(void* p) {
     if (it == g_allocs.end()) { g_errors++; return ret(hipErrorInvalidValue); }
     g_live_bytes -= it->second;
     g_allocs.erase(it);
+    g_alloc_dev.erase(p);
     free(p);
     return hipSuccess;
 }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind, hipStream_t s) {
     if (inject("hipMemcpyAsync")) return ret(hipErrorUnknown);
-    hipstub_enqueue(s, [=] { memcpy(dst, src, bytes); });
+    hipstub_enqueue(s, [=] { hipstub_log("copy", dst, src, bytes, 1, bytes); memcpy(dst, src, bytes); });
     return hipSuccess;
 }
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind k) {
@@ -181,17 +198,24 @@ hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind k) 
 hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t s) {
     if (inject("hipMemcpy2DAsync")) return ret(hipErrorUnknown);
     if (width > dpitch || width > spitch) return ret(hipErrorInvalidValue);
-    hipstub_enqueue(s, [=] { for (size_t r = 0; r < height; r++) memcpy((char*)dst + r * dpitch, (const char*)src + r * spitch, width); });
+    if (getenv("HIPSTUB_REFUSE_CROSS_2D")) {                  // a runtime that has no strided copy between two devices
+        std::lock_guard<std::mutex> lock(g_mu);
+        auto owner = [&](const void* q) { auto it = g_allocs.upper_bound(const_cast<void*>(q)); if (it == g_allocs.begin()) return -1; --it;
+                                          return (const char*)q < (const char*)it->first + it->second ? g_alloc_dev[it->first] : -1; };
+        const int a = owner(dst), b = owner(src);
+        if (a >= 0 && b >= 0 && a != b) return ret(hipErrorInvalidValue);
+    }
+    hipstub_enqueue(s, [=] { hipstub_log("copy2d", dst, src, width, height, dpitch); for (size_t r = 0; r < height; r++) memcpy((char*)dst + r * dpitch, (const char*)src + r * spitch, width); });
     return hipSuccess;
 }
 hipError_t hipMemcpyPeerAsync(void* dst, int, const void* src, int, size_t bytes, hipStream_t s) {
     if (inject("hipMemcpyPeerAsync")) return ret(hipErrorUnknown);
-    hipstub_enqueue(s, [=] { memcpy(dst, src, bytes); });
+    hipstub_enqueue(s, [=] { hipstub_log("peer", dst, src, bytes, 1, bytes); memcpy(dst, src, bytes); });
     return hipSuccess;
 }
 hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s) {
     if (inject("hipMemsetAsync")) return ret(hipErrorUnknown);
-    hipstub_enqueue(s, [=] { memset(dst, value, bytes); });
+    hipstub_enqueue(s, [=] { hipstub_log("memset", dst, nullptr, bytes, 1, bytes); memset(dst, value, bytes); });
     return hipSuccess;
 }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) {

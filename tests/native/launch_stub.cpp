@@ -34,6 +34,7 @@ static hipError_t stub_render(const CameraDev& cam, const RenderArgs& ra, void* 
     timing_mark(stream, true);
     hipstub_enqueue(stream, [=] {
         g_stub_launches++;
+        hipstub_log("kernel", d_accum, nullptr, (size_t)c.width * 12u, a.rows_local, (size_t)c.width * 12u);
         const unsigned long long token = g_token++;
         volatile unsigned long long* w = static_cast<unsigned long long*>(workspace);
         const size_t n = ws_bytes / sizeof(unsigned long long);
@@ -58,22 +59,29 @@ static hipError_t stub_render(const CameraDev& cam, const RenderArgs& ra, void* 
     return hipSuccess;
 }
 
-hipError_t launch_megakernel(const SceneDev&, const CameraDev& cam, const RenderArgs& ra, float* d_accum, unsigned long long* d_counters, bool,
+hipError_t launch_megakernel(const SceneDev&, const CameraDev& cam, const RenderArgs& ra, const trt_tuning&, float* d_accum, unsigned long long* d_counters, bool,
                              hipStream_t stream) {
     return stub_render(cam, ra, nullptr, 0, d_accum, d_counters, stream);
 }
 size_t wavefront_workspace_bytes(uint32_t width, uint32_t rows) { return (size_t)width * rows * 72u + 64u; }
-hipError_t launch_wavefront(const SceneDev&, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
-                            unsigned long long* d_counters, bool, uint32_t, hipStream_t stream) {
+hipError_t launch_wavefront(const SceneDev&, const CameraDev& cam, const RenderArgs& ra, const trt_tuning&, void* workspace, float* d_accum,
+                            unsigned long long* d_counters, bool, hipStream_t stream) {
     return stub_render(cam, ra, workspace, wavefront_workspace_bytes(cam.width, ra.rows_local), d_accum, d_counters, stream);
 }
-uint32_t streamed_chunk_spp(uint32_t, uint32_t) { return 4; }
-size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t) { return (size_t)width * rows * streamed_chunk_spp(width, rows) * 12u + 256u; }
-const char* streamed_kernel_name(const SceneLayout&, const RenderArgs&) { return "stub"; }
-StreamLaunchPlan streamed_launch_plan(const SceneLayout&, const RenderArgs&, bool) { return StreamLaunchPlan{}; }
-hipError_t launch_streamed(const SceneDev&, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
-                           unsigned long long* d_counters, bool, hipStream_t stream) {
-    return stub_render(cam, ra, workspace, streamed_workspace_bytes(cam.width, ra.rows_local, ra.sample_end - ra.sample_begin), d_accum, d_counters, stream);
+uint32_t streamed_chunk_spp(uint32_t, uint32_t, uint32_t) { return 4; }
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples, uint32_t gb) {
+    const uint32_t chunk = streamed_chunk_spp(width, rows, gb);
+    return (size_t)width * rows * (samples < chunk ? (samples ? samples : 1u) : chunk) * 12u + 256u;
+}
+uint32_t streamed_chunk_that_fits(uint32_t width, uint32_t rows, size_t bytes) { return bytes > 256u ? (uint32_t)((bytes - 256u) / ((size_t)width * rows * 12u)) : 0u; }
+const char* streamed_kernel_name(const SceneLayout&, const RenderArgs&, const trt_tuning&) { return "stub"; }
+StreamLaunchPlan streamed_launch_plan(const SceneLayout&, const RenderArgs&, const trt_tuning&, bool) { return StreamLaunchPlan{}; }
+std::atomic<long> g_stub_short_launches{0};
+hipError_t launch_streamed(const SceneDev&, const CameraDev& cam, const RenderArgs& ra, const trt_tuning& tn, void* workspace, size_t workspace_bytes,
+                           float* d_accum, unsigned long long* d_counters, bool, hipStream_t stream) {
+    if (streamed_chunk_that_fits(cam.width, ra.rows_local, workspace_bytes) == 0u) return hipErrorInvalidValue;
+    if (workspace_bytes < streamed_workspace_bytes(cam.width, ra.rows_local, ra.sample_end - ra.sample_begin, tn.radiance_gb)) g_stub_short_launches++;   // granted less than a full launch
+    return stub_render(cam, ra, workspace, workspace_bytes, d_accum, d_counters, stream);
 }
 hipError_t launch_tonemap_u8(const float*, unsigned long long, float, uint8_t*, hipStream_t) { return hipSuccess; }
 hipError_t launch_sample_batch(const SceneDev&, const trt_sample_point* d_in, uint32_t n, trt_sampled_color* d_out, const RenderArgs&,
@@ -89,3 +97,4 @@ hipError_t launch_sample_batch(const SceneDev&, const trt_sample_point* d_in, ui
 
 extern "C" long launch_stub_corruptions(void) { return trt::g_stub_corruptions.load(); }
 extern "C" long launch_stub_launches(void) { return trt::g_stub_launches.load(); }
+extern "C" long launch_stub_short_launches(void) { return trt::g_stub_short_launches.load(); }

@@ -67,7 +67,9 @@ int main(int argc, char** argv) {
         }
         SceneHost s;
         std::string msg;
-        if (!compile_scene(w, s, msg)) { std::printf("compile failed: %s\n", msg.c_str()); return 1; }
+        trt_scene_options opt = scene_options_builtin();                        // every third world with another placement: same leaf sequence
+        if (r % 3 == 1) { opt.cull_prune = 0.2f + 0.1f * (float)(r % 8); opt.compact_nodes = r & 1; opt.flat_walk = (r >> 1) & 1; opt.top_nodes = (uint32_t)(r % 5) * 31u; }
+        if (!compile_scene(w, opt, s, msg)) { std::printf("compile failed: %s\n", msg.c_str()); return 1; }
         if (check_tree(s.reference, (size_t)n_geo, true, "reference")) return 1;
         if (check_tree(s.culling, (size_t)n_geo, false, "culling")) return 1;
         // same leaf sequence
@@ -80,7 +82,7 @@ int main(int argc, char** argv) {
     World empty;
     SceneHost s;
     std::string msg;
-    if (compile_scene(empty, s, msg)) { std::printf("empty world must fail\n"); return 1; }
+    if (compile_scene(empty, scene_options_builtin(), s, msg)) { std::printf("empty world must fail\n"); return 1; }
     trt_camera cam;
     camera_init(cam, 1.0f, 10.0f, trt_vec3{0, 0, 0}, trt_vec3{0, 0, 1}, trt_vec3{0, 1, 0}, 90.0f, 16, 9);
     std::vector<float> acc = {NAN, -1.0f, 0.5f, 2.0f, INFINITY, 0.0f};

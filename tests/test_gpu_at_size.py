@@ -90,21 +90,21 @@ def test_at_size_frame_properties(trt, case):
 
 
 SCHEDULES = {
-    # (scene at bench size, spp) -> environment variants whose frames must be the default's, bit for bit.  Every knob here is read per launch
-    # or per scene compilation and changes scheduling / placement only: the hand-written box-step loops with and without the resumable-walk
-    # exit, other leaf-stack depths, the other workgroup size, the register-slot walk (a C++ loop), the 32-byte-node walk, other wave budgets.
+    # (scene at bench size, spp) -> variants whose frames must be the default's, bit for bit: trt_tuning fields (per render) or, under
+    # "scene", trt_scene_options fields (per scene compilation).  Each changes scheduling / placement only: the hand-written box-step loops
+    # with and without the resumable-walk exit, other leaf-stack depths, the other workgroup size, the register-slot walk (a C++ loop), the
+    # 32-byte-node walk, other wave budgets, two paths per lane.
     "random_spheres_1080p": (lambda trt: trt.scenes.random_spheres(1920, 1080), 32,
-                             [{"TRT_LDS_STRAGGLERS": "0"}, {"TRT_LDS_STRAGGLERS": "24"}, {"TRT_LEAF_SLOTS": "3"}, {"TRT_BIG_THREADS": "512"},
-                              {"TRT_LDS_LEAF_STACK": "0"}, {"TRT_STREAM_MINW": "5"}, {"TRT_RUNTIME_WALK": "1"}]),
+                             [{"lds_stragglers": 0}, {"lds_stragglers": 24}, {"leaf_slots": 3}, {"stream_big_threads": 512},
+                              {"lds_leaf_stack": 0}, {"stream_waves_per_simd": 5}, {"runtime_walk": 1}]),
     "sphere_grid100k_2160p": (lambda trt: trt.scenes.sphere_grid(100000, 3840, 2160), 4,
-                              [{"TRT_STRAGGLERS": "0"}, {"TRT_STRAGGLERS": "40"}, {"TRT_LEAF_SLOTS": "2"}, {"TRT_COMPACT_NODES": "0"},
-                               {"TRT_STREAM_MINW": "6"}, {"TRT_RAY_POOL": "0"}]),
+                              [{"stragglers": 0}, {"stragglers": 40}, {"leaf_slots": 2}, {"scene": {"compact_nodes": 0}},
+                               {"stream_waves_per_simd": 6}, {"ray_pool": 0}, {"dual_walk": 1}, {"dual_walk": 1, "stream_waves_per_simd": 6}]),
 }
-KNOBS = sorted({k for _, _, variants in SCHEDULES.values() for env in variants for k in env})
 
 
 @pytest.mark.parametrize("case", sorted(SCHEDULES))
-def test_at_size_schedules_agree(trt, monkeypatch, case):
+def test_at_size_schedules_agree(trt, case):
     """Round 3: the box-step loops of the two tree walks are hand-written assembly and both walks are resumable.  At the size and depth
     bench.py measures (1.8e8 / 2.0e8 rays per render), every scheduling variant gives the default's frame and ray count."""
     import torch
@@ -114,13 +114,11 @@ def test_at_size_schedules_agree(trt, monkeypatch, case):
     stream = torch.cuda.current_stream()
     ref = ref_rays = None
     for env in [{}] + variants:
-        for k in KNOBS:
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        pw, pcam = trt.world_from_description(desc)                              # scene compiled under the variant's environment
+        knobs = {k: v for k, v in env.items() if k != "scene"}
+        pw, pcam = trt.world_from_description(desc, **env.get("scene", {}))     # scene compiled with the variant's options
         W, H = pcam.get_image_size()
         r = trt.Renderer(spp, 1, DEPTH, False, desc["background"], seed=1)
+        r.tuning = knobs
         acc = torch.zeros((H, W, 3), device=dev)
         ctr = torch.zeros(16, dtype=torch.int64, device=dev)
         r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream, ctr.data_ptr())

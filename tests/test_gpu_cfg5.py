@@ -5,7 +5,7 @@
    host cores), bit for bit, plus the ray count;
  * oracle parity on 16-row bands at 2 spp rendered AS bands (trt_render_params band layout), top / middle / bottom;
  * the counting kernel's node / sphere / shade counters against the oracle's on those bands (reference-order walk);
- * default walk (16-byte f16 culling nodes) vs 32-byte nodes: frames and ray counts identical on the full frame;
+ * default walk (16-byte f16 culling nodes) vs 32-byte nodes vs two paths per lane: frames and ray counts identical on the full frame;
  * size-independent properties at 4 spp: progressive passes == one pass; multi-shard render == one render."""
 import numpy as np
 import pytest
@@ -24,19 +24,17 @@ def cfg5(trt):
     return trt.scenes.sphere_grid(100000, W, H)
 
 
-def test_cfg5_full_frame_bit_exact_against_the_oracle(trt, orc, cfg5, monkeypatch):
+def test_cfg5_full_frame_bit_exact_against_the_oracle(trt, orc, cfg5):
     desc = cfg5
     ow, ocam = orc.world_from_description(desc)
     cpu, cst = orc.render(ow, ocam, 1, DEPTH, desc["background"], seed=1, nthreads=16)
     frames = {}
-    for name, env in (("default", {}), ("nodes32", {"TRT_COMPACT_NODES": "0"})):
-        monkeypatch.delenv("TRT_COMPACT_NODES", raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)                                 # read when the scene is compiled
-        pw, pcam = trt.world_from_description(desc)
+    for name, options, knobs in (("default", {}, {}), ("nodes32", {"compact_nodes": 0}, {}), ("two paths per lane", {}, {"dual_walk": 1})):
+        pw, pcam = trt.world_from_description(desc, **options)       # trt_scene_options: read when the scene is compiled
         info = pw.get_bvh().info()
         assert info["num_nodes"] == 200001 and info["num_spheres"] == 100001 and info["lds_bytes"] == 0
         r = trt.Renderer(1, 1, DEPTH, False, desc["background"], seed=1)
+        r.tuning = knobs
         frames[name] = r.render(pcam, pw).data
         assert r.last_stats["rays"] == cst["rays"] and r.last_stats["samples"] == W * H, name
         assert np.array_equal(bits(frames[name]), bits(cpu)), f"{name} walk differs from the oracle on the cfg5 frame"

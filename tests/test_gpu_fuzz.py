@@ -80,7 +80,7 @@ def test_large_random_scene_from_global_memory(trt, orc):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_walk_schedules_agree_on_many_rays(trt, monkeypatch, seed):
+def test_walk_schedules_agree_on_many_rays(trt, seed):
     """GPU against GPU, ~10^8 rays per scene (the oracle checks above see ~10^5): the postponed-leaf walk with its slots
     in LDS or in registers, the plain one-slot walk and the megakernel run the same primitive tests and give the same
     frame on mixed random scenes (overlapping spheres and quads, all materials): rounding-level hazards of the
@@ -88,10 +88,9 @@ def test_walk_schedules_agree_on_many_rays(trt, monkeypatch, seed):
     desc = random_scene(300 + seed, n_prims=int(20 + 60 * seed), width=1280, height=800)
     pw, pcam = trt.world_from_description(desc)
     ref_img = ref_stats = None
-    for backend, slots, lds in ((3, "1", "0"), (3, "4", "2"), (3, "4", "0"), (3, "2", "0"), (0, "4", "0"), (3, "8", "2")):
-        monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
-        monkeypatch.setenv("TRT_LDS_LEAF_STACK", lds)
+    for backend, slots, lds in ((3, 1, 0), (3, 4, 2), (3, 4, 0), (3, 2, 0), (0, 4, 0), (3, 8, 2)):
         r = trt.Renderer(16, 1, 16, False, desc["background"], seed=11, backend=backend)
+        r.tuning = {"leaf_slots": slots, "lds_leaf_stack": lds}
         img = r.render(pcam, pw, collect_stats=2)
         st = dict(r.last_stats)
         if ref_img is None:
@@ -103,22 +102,18 @@ def test_walk_schedules_agree_on_many_rays(trt, monkeypatch, seed):
 
 
 @pytest.mark.parametrize("spheres_only", [False, True])
-def test_global_memory_walks_agree_on_many_rays(trt, monkeypatch, spheres_only):
+def test_global_memory_walks_agree_on_many_rays(trt, spheres_only):
     """Scenes walked from global memory (hot part > 64 KB), ~10^8 rays: the 16-byte-node walk (f16 boxes, exact leaf boxes
     re-tested), the 32-byte-node walk, the plain one-slot walk and the megakernel - frames, ray counts and primitive-test
     counters."""
     desc = random_scene(500 + int(spheres_only), n_prims=3000, width=1280, height=800, p_sphere=1.0 if spheres_only else 0.5)
     ref_img = ref_stats = None
-    for backend, compact, slots in ((3, "0", "1"), (3, "1", None), (3, "0", None), (3, "1", "2"), (0, "0", None)):
-        monkeypatch.setenv("TRT_COMPACT_NODES", compact)                            # read when the scene is compiled
-        if slots is None:
-            monkeypatch.delenv("TRT_LEAF_SLOTS", raising=False)
-        else:
-            monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
-        pw, pcam = trt.world_from_description(desc)
+    for backend, compact, slots, dual in ((3, 0, 1, 0), (3, 1, None, 0), (3, 0, None, 0), (3, 1, 2, 0), (0, 0, None, 0), (3, 1, None, 1), (3, 1, 3, 1)):
+        pw, pcam = trt.world_from_description(desc, compact_nodes=compact)         # trt_scene_options: read when the scene is compiled
         assert pw.get_bvh().info()["lds_bytes"] == 0
-        assert (pw.get_bvh().compact_nodes() is not None) == (compact == "1")
+        assert (pw.get_bvh().compact_nodes() is not None) == (compact == 1)
         r = trt.Renderer(16, 1, 16, False, desc["background"], seed=13, backend=backend)
+        r.tuning = dict({"dual_walk": dual}, **({} if slots is None else {"leaf_slots": slots}))
         img = r.render(pcam, pw, collect_stats=2)
         st = dict(r.last_stats)
         plain = r.render(pcam, pw)                                                   # production kernel

@@ -45,11 +45,7 @@ def render_both(trt, orc, desc, spp, depth, seed=1, nthreads=8, stats=True, **ov
         assert_bit_equal(own.data, img.data, "counting kernel on the culling tree")
         for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
             assert r.last_stats[k] == gst[k], k
-        os.environ["TRT_LEAF_SLOTS"] = "1"
-        try:
-            plain = r.render(pcam, pw, collect_stats=2, **over)
-        finally:
-            del os.environ["TRT_LEAF_SLOTS"]
+        plain = r.render(pcam, pw, collect_stats=2, tuning={"leaf_slots": 1}, **over)
         assert_bit_equal(plain.data, img.data, "counting kernel on the culling tree, one leaf slot")
         for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
             assert r.last_stats[k] == gst[k], k
@@ -125,15 +121,14 @@ def test_large_scene_traversed_from_global_memory(trt, orc):
         assert gst[k] == cst[k], k
 
 
-def test_large_scene_with_top_levels_cached_in_lds(trt, orc, monkeypatch):
-    """Optional placement (env TRT_TOP_NODES): the culling tree's top levels first, copied into LDS; same bits."""
-    monkeypatch.setenv("TRT_TOP_NODES", "255")
+def test_large_scene_with_top_levels_cached_in_lds(trt, orc):
+    """Optional placement (trt_scene_options.top_nodes): the culling tree's top levels first, copied into LDS; same bits."""
     desc = trt.scenes.sphere_grid(4000, 96, 54)
-    pw, _ = trt.world_from_description(desc)
+    pw, _ = trt.world_from_description(desc, top_nodes=255)
     info = pw.get_bvh().info()
     assert 0 < info["lds_bytes"] <= 255 * 32
     for backend in (0, 1, 3):
-        pw, pcam = trt.world_from_description(desc)
+        pw, pcam = trt.world_from_description(desc, top_nodes=255)
         gpu = trt.Renderer(4, 1, 50, False, desc["background"], backend=backend).render(pcam, pw).data
         ow, ocam = orc.world_from_description(desc)
         cpu, _ = orc.render(ow, ocam, 4, 50, desc["background"], nthreads=8)

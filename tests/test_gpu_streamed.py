@@ -47,11 +47,10 @@ def test_ragged_image_sizes(trt, orc, wh):
     assert gst["samples"] == wh[0] * wh[1] * 3
 
 
-@pytest.mark.parametrize("minw", ["5", "6", "7"])
-def test_wave_budget_never_changes_the_frame(trt, orc, minw, monkeypatch):
-    monkeypatch.setenv("TRT_STREAM_MINW", minw)
+@pytest.mark.parametrize("minw", [5, 6, 7])
+def test_wave_budget_never_changes_the_frame(trt, orc, minw):
     desc = trt.scenes.random_spheres(96, 64)
-    gpu, gst = render(trt, desc, 4, 20)
+    gpu, gst = render(trt, desc, 4, 20, tuning={"stream_waves_per_simd": minw})
     cpu, cst = oracle(orc, desc, 4, 20)
     assert_bit_equal(gpu, cpu, f"streamed minw {minw}")
     assert gst["node_tests"] == cst["node_tests"]
@@ -143,7 +142,7 @@ def test_frames_match_the_reference_renders_statistically(trt):
 
 
 @pytest.mark.parametrize("scene", ["random_spheres", "cornell"])
-def test_leaf_slots_are_scheduling_only(trt, monkeypatch, scene):
+def test_leaf_slots_are_scheduling_only(trt, scene):
     """The postponed-leaf walk (rt_path.h walk_fast / walk_fast_lds) must run exactly the reference's primitive tests:
     frames, ray counts and primitive-test counters are identical for 1 slot (plain while-while), 2, 4 (default) and 8,
     with the slots in registers or in LDS, on scenes large enough for grazing hits to occur (an earlier version that
@@ -153,10 +152,9 @@ def test_leaf_slots_are_scheduling_only(trt, monkeypatch, scene):
     pw, pcam = trt.world_from_description(desc)
     r = trt.Renderer(16, 1, 50, False, desc["background"], seed=5, backend=STREAMED)
     ref_img = ref_stats = None
-    for slots, lds in (("1", "0"), ("2", "0"), ("4", "0"), ("1", "2"), ("4", "2"), ("8", "2"), ("4", "1")):
-        monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
-        monkeypatch.setenv("TRT_LDS_LEAF_STACK", lds)                               # 0 registers, 2 LDS, 1 LDS where it costs no occupancy
-        img = r.render(pcam, pw, collect_stats=2)
+    for slots, lds in ((1, 0), (2, 0), (4, 0), (1, 2), (4, 2), (8, 2), (4, 1)):
+        # lds_leaf_stack: 0 registers, 2 LDS, 1 LDS where it costs no occupancy
+        img = r.render(pcam, pw, collect_stats=2, tuning={"leaf_slots": slots, "lds_leaf_stack": lds})
         st = r.last_stats
         if ref_img is None:
             ref_img, ref_stats = img.data.copy(), dict(st)
@@ -164,8 +162,6 @@ def test_leaf_slots_are_scheduling_only(trt, monkeypatch, scene):
         assert np.array_equal(img.data.view(np.uint32), ref_img.view(np.uint32)), (slots, lds)
         for k in ("samples", "rays", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades"):
             assert st[k] == ref_stats[k], (slots, lds, k)
-    monkeypatch.delenv("TRT_LEAF_SLOTS")
-    monkeypatch.delenv("TRT_LDS_LEAF_STACK")
     plain = r.render(pcam, pw)                                                      # production (non-counting) kernel, defaults
     assert np.array_equal(plain.data.view(np.uint32), ref_img.view(np.uint32))
     assert r.last_stats["rays"] == ref_stats["rays"]
@@ -213,7 +209,7 @@ def test_device_tonemap_is_bit_exact_against_the_oracle(trt, orc):
     assert list(out.cpu().numpy()[[1, 2, 3, 7, 8, 9]]) == [0, 0, 0, 254, 254, 254]
 
 
-def test_lockstep_leaf_list_is_scheduling_only(trt, orc, monkeypatch):
+def test_lockstep_leaf_list_is_scheduling_only(trt, orc):
     """Scenes with at most 32 primitives are walked as a lock-step leaf list (rt_path.h walk_flat, wave-uniform nodes
     from the scalar cache) instead of through the culling tree: same frame, same primitive tests, as the tree walk,
     the plain one-slot walk and the oracle."""
@@ -221,14 +217,10 @@ def test_lockstep_leaf_list_is_scheduling_only(trt, orc, monkeypatch):
     ow, ocam = orc.world_from_description(desc)
     cpu, cst = orc.render(ow, ocam, 8, 50, desc["background"], seed=9, nthreads=8)
     results = []
-    for flat, slots in (("0", "1"), ("1", "0"), ("1", "2"), ("1", "12"), ("0", "0")):
-        monkeypatch.setenv("TRT_FLAT_WALK", flat)                                   # read when the scene is compiled
-        if slots == "0":
-            monkeypatch.delenv("TRT_LEAF_SLOTS", raising=False)
-        else:
-            monkeypatch.setenv("TRT_LEAF_SLOTS", slots)
-        pw, pcam = trt.world_from_description(desc)
+    for flat, slots in ((0, 1), (1, 0), (1, 2), (1, 12), (0, 0)):
+        pw, pcam = trt.world_from_description(desc, flat_walk=flat)                 # trt_scene_options: read when the scene is compiled
         r = trt.Renderer(8, 1, 50, False, desc["background"], seed=9, backend=STREAMED)
+        r.tuning = {"leaf_slots": slots}                                            # 0 = by launch plan
         img = r.render(pcam, pw, collect_stats=2)
         results.append((flat, slots, img.data.copy(), dict(r.last_stats)))
         plain = r.render(pcam, pw)                                                  # production kernel
@@ -243,7 +235,7 @@ def test_lockstep_leaf_list_is_scheduling_only(trt, orc, monkeypatch):
     assert tree["node_tests"] < flat_default["node_tests"]
 
 
-def test_full_size_schedules_agree_cornell_2048(trt, monkeypatch):
+def test_full_size_schedules_agree_cornell_2048(trt):
     """BASELINE's full frame size, 64 spp (1.9e9 rays per render): the shipped schedule (lock-step leaf list, 6 LDS
     slots), the culling-tree walk with LDS slots, the plain one-slot tree walk and the megakernel give the same frame
     and the same ray count - every scheduling layer added on top of the reference's walk is checked at full size."""
@@ -252,15 +244,10 @@ def test_full_size_schedules_agree_cornell_2048(trt, monkeypatch):
     desc = trt.scenes.cornell(2048, 2048)
     stream = torch.cuda.current_stream()
     ref = ref_rays = None
-    for backend, flat, slots, lds in ((STREAMED, "1", None, None), (STREAMED, "0", None, None), (STREAMED, "0", "1", "0"), (0, "0", "1", "0")):
-        monkeypatch.setenv("TRT_FLAT_WALK", flat)
-        for k, v in (("TRT_LEAF_SLOTS", slots), ("TRT_LDS_LEAF_STACK", lds)):
-            if v is None:
-                monkeypatch.delenv(k, raising=False)
-            else:
-                monkeypatch.setenv(k, v)
-        pw, pcam = trt.world_from_description(desc)
+    for backend, flat, slots, lds in ((STREAMED, 1, None, None), (STREAMED, 0, None, None), (STREAMED, 0, 1, 0), (0, 0, 1, 0)):
+        pw, pcam = trt.world_from_description(desc, flat_walk=flat)
         r = trt.Renderer(64, 1, 50, False, desc["background"], seed=1, backend=backend)
+        r.tuning = {k: v for k, v in (("leaf_slots", slots), ("lds_leaf_stack", lds)) if v is not None}
         acc = torch.zeros((2048, 2048, 3), device=dev)
         ctr = torch.zeros(16, dtype=torch.int64, device=dev)
         r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream, ctr.data_ptr())
@@ -274,7 +261,7 @@ def test_full_size_schedules_agree_cornell_2048(trt, monkeypatch):
         assert torch.equal(acc.view(torch.int32), ref.view(torch.int32)), (backend, flat, slots, lds)
 
 
-def test_full_baseline_config_bit_identical_across_backends(trt, monkeypatch):
+def test_full_baseline_config_bit_identical_across_backends(trt):
     """BASELINE configs[3] in full - Cornell 2048x2048, 4096 spp, depth 50, 1.2e11 rays - rendered by the shipped schedule
     (streamed, lock-step leaf list, LDS slots) and by the megakernel with the plain one-slot tree walk: the two frames
     are bit-identical and trace the same number of rays."""
@@ -283,13 +270,10 @@ def test_full_baseline_config_bit_identical_across_backends(trt, monkeypatch):
     desc = trt.scenes.cornell(2048, 2048)
     stream = torch.cuda.current_stream()
     frames, rays = [], []
-    for backend, env in ((STREAMED, {}), (0, {"TRT_LEAF_SLOTS": "1", "TRT_FLAT_WALK": "0"})):
-        for k in ("TRT_LEAF_SLOTS", "TRT_FLAT_WALK"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        pw, pcam = trt.world_from_description(desc)
+    for backend, knobs, options in ((STREAMED, {}, {}), (0, {"leaf_slots": 1}, {"flat_walk": 0})):
+        pw, pcam = trt.world_from_description(desc, **options)
         r = trt.Renderer(4096, 1, 50, False, desc["background"], seed=1, backend=backend)
+        r.tuning = knobs
         acc = torch.zeros((2048, 2048, 3), device=dev)
         ctr = torch.zeros(16, dtype=torch.int64, device=dev)
         r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream, ctr.data_ptr())

@@ -70,12 +70,11 @@ def test_ragged_image_sizes(trt, orc, wh):
     assert gst["samples"] == wh[0] * wh[1] * 3
 
 
-@pytest.mark.parametrize("serve_min", ["1", "8", "48", "64"])
-def test_refill_threshold_never_changes_the_frame(trt, orc, serve_min, monkeypatch):
-    """The EXTEND phase's serve threshold is a scheduling knob: every value gives the same bits."""
-    monkeypatch.setenv("TRT_WF_SERVE_MIN", serve_min)
+@pytest.mark.parametrize("serve_min", [1, 8, 48, 64])
+def test_refill_threshold_never_changes_the_frame(trt, orc, serve_min):
+    """The EXTEND phase's serve threshold (trt_tuning.wf_serve_min) is a scheduling knob: every value gives the same bits."""
     desc = trt.scenes.random_spheres(96, 64)
-    gpu, gst = render_wf(trt, desc, 4, 20)
+    gpu, gst = render_wf(trt, desc, 4, 20, tuning={"wf_serve_min": serve_min})
     cpu, cst = oracle(orc, desc, 4, 20)
     assert_bit_equal(gpu, cpu, f"serve_min {serve_min}")
     assert gst["node_tests"] == cst["node_tests"]

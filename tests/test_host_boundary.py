@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(trt):
     for name in sorted(declared):
         assert hasattr(raw, name), f"{name} declared in tinyrt.h but not exported"
     assert declared == set(_lib.SIGNATURES), "ctypes table and header disagree"
-    assert trt.lib.trt_abi_version() == trt._lib.ABI_VERSION == 2
+    assert trt.lib.trt_abi_version() == trt._lib.ABI_VERSION == 3
 
 
 def test_pod_layouts_match_reference(trt):
@@ -249,17 +249,16 @@ def test_compact_nodes_are_the_culling_tree_rounded_outward(trt):
     assert small.get_bvh().compact_nodes() is None
 
 
-def test_f16_outward_rounding_handles_the_edges(trt, monkeypatch):
-    """Coordinates beyond the f16 range, zeros, subnormals and exact f16 values (TRT_COMPACT_NODES=1 forces the array
+def test_f16_outward_rounding_handles_the_edges(trt):
+    """Coordinates beyond the f16 range, zeros, subnormals and exact f16 values (trt_scene_options.compact_nodes = 1 forces the array
     for a small scene)."""
-    monkeypatch.setenv("TRT_COMPACT_NODES", "1")
     mats = [("m", 0, (0.5, 0.5, 0.5), 0.0)]
     geos = [("sphere", (1.0e5, 0.0, 0.0), 1.0, "m"), ("sphere", (-7.0e4, 3.0e-6, -3.0e-6), 0.5, "m"),
             ("sphere", (0.5, 2.0, -1.0), 0.25, "m"), ("sphere", (1.0e-7, -1.0e-7, 0.0), 1.0e-7, "m"),
             ("quad", (0.0, 0.0, 0.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0), "m"), ("sphere", (65504.0, -65504.0, 2049.0), 1.0, "m")]
     cam = dict(focus_distance=1.0, defocus_angle=0.0, position=(0.0, 0.0, 5.0), look_at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0),
                vertical_fov=40.0, width=8, height=8)
-    pw, _ = trt.world_from_description(dict(name="edges", materials=mats, geometries=geos, camera=cam, background=(0, 0, 0)))
+    pw, _ = trt.world_from_description(dict(name="edges", materials=mats, geometries=geos, camera=cam, background=(0, 0, 0)), compact_nodes=1)
     sc = pw.get_bvh()
     lo16, hi16, _ = sc.compact_nodes()
     box, _, _ = sc.cull_nodes()
@@ -326,9 +325,9 @@ def test_c_band_layout_equals_the_python_one(trt):
 
 
 # ---- round 3: the streamed backend's launch plan and the multi-GPU gather, checked without a device ----
-def _plan(trt, scene, cam, **over):
+def _plan(trt, scene, cam, tuning=None, **over):
     import ctypes as C
-    p = trt.Renderer(64, 1, 50, False, (0.1, 0.1, 0.1)).params(**over)
+    p = trt.Renderer(64, 1, 50, False, (0.1, 0.1, 0.1)).params(tuning=tuning, **over)
     out = trt._lib.LaunchPlan()
     trt._lib.check(trt.lib.trt_streamed_launch_plan(scene._h, C.byref(cam.pod), C.byref(p), C.byref(out)))
     return out.as_dict()
@@ -342,7 +341,10 @@ def _check_plan(pl, stats, tag):
     assert pl["kernel_threads"] == pl["threads_per_workgroup"] and pl["threads_per_workgroup"] in (256, 512, 768), tag
     assert 1 <= pl["leaf_slots"] <= 16, tag
     if pl["lds_leaf_stack"]:
-        assert pl["lds_bytes"] == al + pl["threads_per_workgroup"] * pl["leaf_slots"] * 8 + (pl["threads_per_workgroup"] * 36 if pl["ray_pool"] else 0), tag
+        stacks = 2 if pl["dual_walk"] else 1                                      # two paths per lane: two leaf stacks per lane
+        assert pl["lds_bytes"] == al + stacks * pl["threads_per_workgroup"] * pl["leaf_slots"] * 8 + (pl["threads_per_workgroup"] * 36 if pl["ray_pool"] else 0), tag
+        if pl["dual_walk"]:
+            assert pl["walk"] == 3 and pl["ray_pool"] and pl["specialised"] and pl["leaf_slots"] >= 2 and not stats, tag      # a parked walk needs two slots
     else:
         assert pl["lds_bytes"] == pl["scene_lds_bytes"] and not pl["ray_pool"] and pl["walk"] == 5, tag
     assert pl["lds_bytes"] <= 160 * 1024 and pl["lds_bytes"] * pl["workgroups_per_cu"] <= 160 * 1024, tag
@@ -360,9 +362,9 @@ def _check_plan(pl, stats, tag):
     assert pl["workspace_bytes"] > 0 and pl["chunk_spp"] in (1, 2, 4, 8, 16, 32, 64, 128, 256), tag
 
 
-def test_streamed_launch_plan_invariants_for_every_scene_size_and_knob(trt, monkeypatch):
+def test_streamed_launch_plan_invariants_for_every_scene_size_and_knob(trt):
     """Round 2's GPU suite dumped core ONCE under TRT_STREAM_MINW=8 and nothing kept the reason.  Part of the
-    audit: every (scene size, knob) combination the environment can ask for yields a plan whose LDS parts add up, whose stack is
+    audit: every (scene size, trt_tuning) combination a caller can ask for yields a plan whose LDS parts add up, whose stack is
     deep enough for its walk, and for which a kernel instantiation of that exact shape exists - checked here for all of them,
     without a GPU."""
     import itertools
@@ -373,41 +375,33 @@ def test_streamed_launch_plan_invariants_for_every_scene_size_and_knob(trt, monk
         scenes.append((f"grid{n}", trt.scenes.sphere_grid(n, 64, 48)))
     scenes.append(("grid4000", trt.scenes.sphere_grid(4000, 64, 48)))            # read from global memory
     knobs = {
-        "TRT_STREAM_MINW": (None, "4", "5", "6", "7", "8", "9"),
-        "TRT_LEAF_SLOTS": (None, "1", "2", "3", "4", "8", "16", "64"),
-        "TRT_LDS_LEAF_STACK": (None, "0", "2"),
-        "TRT_RAY_POOL": (None, "0"),
-        "TRT_BIG_THREADS": (None, "512", "768"),
-        "TRT_RUNTIME_WALK": (None, "1"),
+        "stream_waves_per_simd": (None, 4, 5, 6, 7, 8, 9),
+        "leaf_slots": (None, 1, 2, 3, 4, 8, 16, 64),
+        "lds_leaf_stack": (None, 0, 2),
+        "ray_pool": (None, 0),
+        "stream_big_threads": (None, 512, 768),
+        "runtime_walk": (None, 1),
+        "dual_walk": (None, 1),
     }
     n_checked = 0
     modes = set()
     for name, desc in scenes:
-        for flat_env in ((None, "0") if name in ("cornell", "grid31") else (None,)):
-            if flat_env is None:
-                monkeypatch.delenv("TRT_FLAT_WALK", raising=False)
-            else:
-                monkeypatch.setenv("TRT_FLAT_WALK", flat_env)
-            w, cam = trt.world_from_description(desc)
+        for flat in ((None, 0) if name in ("cornell", "grid31") else (None,)):
+            w, cam = trt.world_from_description(desc, **({} if flat is None else {"flat_walk": flat}))
             scene = w.get_bvh()
-            monkeypatch.delenv("TRT_FLAT_WALK", raising=False)
             for combo in itertools.product(*knobs.values()):
-                for k, v in zip(knobs, combo):
-                    if v is None:
-                        monkeypatch.delenv(k, raising=False)
-                    else:
-                        monkeypatch.setenv(k, v)
+                if combo[-1] == 1 and name != "grid4000":
+                    continue                                                      # two paths per lane exist for scenes in global memory only
+                tn = {k: v for k, v in zip(knobs, combo) if v is not None}
                 for stats in (0, 1, 2):
-                    pl = _plan(trt, scene, cam, collect_stats=stats)
-                    _check_plan(pl, stats, (name, flat_env, combo, stats, pl))
-                    modes.add((pl["scene_mode"], pl["walk"], pl["threads_per_workgroup"], pl["ray_pool"]))
+                    pl = _plan(trt, scene, cam, tuning=tn, collect_stats=stats)
+                    _check_plan(pl, stats, (name, flat, combo, stats, pl))
+                    modes.add((pl["scene_mode"], pl["walk"], pl["threads_per_workgroup"], pl["ray_pool"], pl["dual_walk"]))
                     n_checked += 1
     assert n_checked > 20000 and len(modes) >= 8, (n_checked, sorted(modes))
 
 
-def test_default_plans_of_the_three_baseline_scenes(trt, monkeypatch):
-    for k in ("TRT_STREAM_MINW", "TRT_LEAF_SLOTS", "TRT_LDS_LEAF_STACK", "TRT_RAY_POOL", "TRT_BIG_THREADS", "TRT_RUNTIME_WALK", "TRT_FLAT_WALK"):
-        monkeypatch.delenv(k, raising=False)
+def test_default_plans_of_the_three_baseline_scenes(trt):
     w, cam = trt.world_from_description(trt.scenes.cornell(64, 64))
     pl = _plan(trt, w.get_bvh(), cam)
     assert (pl["walk"], pl["threads_per_workgroup"], pl["waves_per_simd"], pl["leaf_slots"], pl["ray_pool"], pl["specialised"]) == (2, 256, 6, 7, 1, 1)

@@ -61,6 +61,10 @@ def header_structs():
             decl = decl.strip()
             if not decl:
                 continue
+            ptr = re.match(r"(.*\*)\s*(\w+)$", decl)                     # 'const trt_tuning *tuning'
+            if ptr:
+                fields.append((ptr.group(2), c_type_to_rust(ptr.group(1))))
+                continue
             ctype, names = decl.split(None, 1)
             for nm in names.split(","):
                 nm = nm.strip()

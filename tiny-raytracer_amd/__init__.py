@@ -5,16 +5,18 @@ importlib.import_module("tiny-raytracer_amd") or through the top-level alias mod
 """
 from . import scenes  # noqa: F401
 from ._lib import (BACKEND_AUTO, BACKEND_MEGAKERNEL, BACKEND_STREAMED, BACKEND_WAVEFRONT, DIELECTRIC, LAMBERTIAN, LIGHT, METAL, CameraPOD,  # noqa: F401
-                   Material, Ray, RenderParams, SampledColor, SamplePoint, Stats, TinyRTError, Vec3, lib)
+                   Material, Ray, RenderParams, SampledColor, SamplePoint, SceneOptions, Stats, TinyRTError, Tuning, Vec3, lib)
 from .api import (Camera, Dielectric, Image, Lambertian, Light, Metal, Quad, Renderer, Scene, Sphere, World,  # noqa: F401
-                  sample_batch, tonemap_u8_device)
+                  sample_batch, scene_options, tonemap_u8_device, tuning)
 
 _MATERIAL_CTORS = {LAMBERTIAN: lambda a, p: Lambertian(a), METAL: Metal, DIELECTRIC: Dielectric,
                    LIGHT: lambda a, p: Light(a)}
 
 
-def world_from_description(desc):
-    """Build a product World (and its Camera) from a scenes.* description."""
+def world_from_description(desc, **scene_options):
+    """Build a product World (and its Camera) from a scenes.* description; `scene_options`: trt_scene_options fields its get_bvh() uses."""
     w = scenes.build_world(desc, World(), lambda k, a, p: _MATERIAL_CTORS[k](a, p), Sphere, Quad)
+    if scene_options:
+        w.scene_options = scene_options
     cam = Camera(**desc["camera"])
     return w, cam

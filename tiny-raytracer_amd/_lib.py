@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("TRT_LIB_PATH") or os.path.join(_HERE, "libtinyrt.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 TRT_OK = 0
-ABI_VERSION = 2          # include/tinyrt.h TRT_ABI_VERSION
+ABI_VERSION = 3          # include/tinyrt.h TRT_ABI_VERSION
 ERR_INVALID_ARG, ERR_DUPLICATE, ERR_NOT_FOUND, ERR_HIP, ERR_NO_DEVICE, ERR_OOM = -1, -2, -3, -4, -5, -6
 LAMBERTIAN, METAL, DIELECTRIC, LIGHT = 0, 1, 2, 3
 BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, BACKEND_AUTO, BACKEND_STREAMED = 0, 1, 2, 3
@@ -66,10 +66,27 @@ class LaunchPlan(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in
                 ("scene_mode", "threads_per_workgroup", "waves_per_simd", "workgroups_per_cu", "lds_bytes", "scene_lds_bytes",
                  "leaf_slots", "lds_leaf_stack", "ray_pool", "walk", "specialised", "has_kernel", "kernel_waves_per_simd",
-                 "kernel_threads", "kernel_walk", "kernel_ray_pool", "kernel_counting", "chunk_spp")] + [("workspace_bytes", C.c_uint64)]
+                 "kernel_threads", "kernel_walk", "kernel_ray_pool", "kernel_counting", "chunk_spp", "dual_walk")] + [("workspace_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class Tuning(C.Structure):
+    """tinyrt.h trt_tuning: scheduling / placement knobs of a render; every value renders the same frame."""
+    FIELDS = ("stream_waves_per_simd", "stream_big_threads", "stream_batch_spp", "radiance_gb", "leaf_slots", "lds_leaf_stack", "ray_pool",
+              "stragglers", "lds_stragglers", "dual_walk", "runtime_walk", "xcd_remap", "mega_waves_per_simd", "mega_threads",
+              "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min")
+    _fields_ = [(n, C.c_uint32) for n in FIELDS] + [("reserved", C.c_uint32 * 7)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n in self.FIELDS}
+
+
+class SceneOptions(C.Structure):
+    """tinyrt.h trt_scene_options: how a scene is compiled (placement only) and how much idle device scratch its handle keeps."""
+    _fields_ = [("cull_prune", C.c_float), ("flat_walk", C.c_int32), ("compact_nodes", C.c_int32), ("top_nodes", C.c_uint32),
+                ("scratch_cap_bytes", C.c_uint64), ("reserved", C.c_uint32 * 6)]
 
 
 class RenderParams(C.Structure):
@@ -77,13 +94,13 @@ class RenderParams(C.Structure):
                 ("seed", C.c_uint32), ("backend", C.c_uint32),
                 ("sample_begin", C.c_uint32), ("sample_end", C.c_uint32), ("accumulate", C.c_uint32),
                 ("band_rows", C.c_uint32), ("band_stride", C.c_uint32), ("band_offset", C.c_uint32),
-                ("rows_local", C.c_uint32), ("collect_stats", C.c_uint32)]
+                ("rows_local", C.c_uint32), ("collect_stats", C.c_uint32), ("tuning", C.POINTER(Tuning))]
 
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("rays", C.c_uint64), ("node_tests", C.c_uint64),
                 ("sphere_tests", C.c_uint64), ("quad_plane_tests", C.c_uint64), ("quad_inside_tests", C.c_uint64),
-                ("shades", C.c_uint64), ("kernel_ms", C.c_double), ("wave_trips", C.c_uint64 * 4)]
+                ("shades", C.c_uint64), ("kernel_ms", C.c_double), ("wave_trips", C.c_uint64 * 4), ("gather_per_band", C.c_uint64)]
 
     def as_dict(self):
         d = {n: getattr(self, n) for n, _ in self._fields_ if n != "wave_trips"}
@@ -102,6 +119,9 @@ SIGNATURES = {
     "trt_world_num_geometries": (C.c_int, [C.c_void_p]),
     "trt_world_num_materials": (C.c_int, [C.c_void_p]),
     "trt_scene_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "trt_scene_options_default": (None, [C.POINTER(SceneOptions)]),
+    "trt_scene_create_ex": (C.c_int, [C.c_void_p, C.POINTER(SceneOptions), C.POINTER(C.c_void_p)]),
+    "trt_tuning_default": (None, [C.POINTER(Tuning)]),
     "trt_scene_destroy": (None, [C.c_void_p]),
     "trt_scene_trim": (C.c_int, [C.c_void_p]),
     "trt_scene_get_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _lib
 from ._lib import (BACKEND_MEGAKERNEL, BACKEND_WAVEFRONT, DIELECTRIC, LAMBERTIAN, LIGHT, METAL, CameraPOD, Material,
-                   RenderParams, SampledColor, SamplePoint, SceneInfo, Stats, TinyRTError, Vec3, check, lib)
+                   RenderParams, SampledColor, SamplePoint, SceneInfo, SceneOptions, Stats, TinyRTError, Tuning, Vec3, check, lib)
 
 
 def _v(v):
@@ -55,12 +55,37 @@ class Quad:
         self.corner, self.u, self.v, self.material = _v(corner), _v(u), _v(v), int(material)
 
 
+def scene_options(**over):
+    """The library's default trt_scene_options with `over` applied."""
+    opt = SceneOptions()
+    lib.trt_scene_options_default(C.byref(opt))
+    for k, v in over.items():
+        if k not in dict(SceneOptions._fields_) or k == "reserved":
+            raise TypeError(f"unknown scene option {k!r}")
+        setattr(opt, k, v)
+    return opt
+
+
+def tuning(**over):
+    """The library's default trt_tuning (built-in values, overridden once at load by TRT_* environment variables) with `over` applied."""
+    t = Tuning()
+    lib.trt_tuning_default(C.byref(t))
+    for k, v in over.items():
+        if k not in Tuning.FIELDS:
+            raise TypeError(f"unknown tuning field {k!r}")
+        setattr(t, k, int(v))
+    return t
+
+
 class Scene:
     """World::get_bvh(): the reference-order BVH, packed for the GPU (uploaded on first render)."""
 
-    def __init__(self, world):
+    def __init__(self, world, **options):
+        """options: fields of tinyrt.h trt_scene_options (cull_prune, flat_walk, compact_nodes, top_nodes, scratch_cap_bytes) - placement
+        only: whatever they are, the scene renders the same frames."""
         self._h = C.c_void_p()
-        check(lib.trt_scene_create(world._h, C.byref(self._h)))
+        opt = scene_options(**options)
+        check(lib.trt_scene_create_ex(world._h, C.byref(opt), C.byref(self._h)))
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -106,6 +131,17 @@ class World:
         self._h = C.c_void_p()
         check(lib.trt_world_create(C.byref(self._h)))
         self._scene = None
+        self._scene_options = {}
+
+    @property
+    def scene_options(self):
+        """trt_scene_options fields get_bvh() compiles the scene with (placement only: the frames never change)."""
+        return dict(self._scene_options)
+
+    @scene_options.setter
+    def scene_options(self, options):
+        self._scene_options = dict(options)
+        self._scene = None
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -135,9 +171,12 @@ class World:
     def num_geometries(self):
         return lib.trt_world_num_geometries(self._h)
 
-    def get_bvh(self):
+    def get_bvh(self, **options):
+        """World::get_bvh (world.rs:43-45).  `options`: see Scene; a scene compiled with options is not cached."""
+        if options:
+            return Scene(self, **options)
         if self._scene is None:
-            self._scene = Scene(self)
+            self._scene = Scene(self, **self._scene_options)
         return self._scene
 
 
@@ -191,9 +230,16 @@ class Renderer:
         self.seed = int(seed)
         self.backend = int(backend)
         self.last_stats = None
+        self.tuning = {}                 # trt_tuning fields this renderer overrides (scheduling only: frames never change)
 
-    def params(self, **over):
+    def params(self, tuning=None, **over):
+        """trt_render_params for this renderer; `tuning`: dict of trt_tuning fields for this call (on top of self.tuning)."""
         p = RenderParams()
+        knobs = dict(self.tuning)
+        knobs.update(tuning or {})
+        if knobs:
+            p._tuning_keepalive = globals()["tuning"](**knobs)       # the POD holds a pointer: keep the struct alive with it
+            p.tuning = C.pointer(p._tuning_keepalive)
         p.samples_per_pixel = self.samples_per_pixel
         p.max_bounces = self.max_bounces
         p.background = self.background_color

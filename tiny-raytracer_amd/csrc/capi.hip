@@ -122,8 +122,7 @@ struct trt_scene {
     std::mutex mu;
     std::condition_variable cv;
     std::unordered_map<int, DeviceCache> dev;     // device ordinal -> cached device resources
-    size_t scratch_cap_bytes = (size_t)32 << 30;  // idle scratch (workspaces + context frames) kept per device; TRT_SCRATCH_CAP_MB.  One full-size
-                                                  // streamed workspace is up to 16 GB (streamed_chunk_spp): the cap must hold it, or every render re-allocates
+    size_t scratch_cap_bytes = (size_t)32 << 30;  // idle scratch (workspaces + context frames) kept per device: trt_scene_options.scratch_cap_bytes
 };
 
 namespace {
@@ -142,6 +141,38 @@ int fail_hip(hipError_t e, const char* what) {
         hipError_t e_ = (call);                              \
         if (e_ != hipSuccess) return fail_hip(e_, #call);    \
     } while (0)
+
+// The library defaults: the built-in values (kernels.h tuning_builtin, scene_host.cpp scene_options_builtin), overridden by the TRT_*
+// environment variables ONCE, when the first call needs them (a function-local static: initialised exactly once, thread-safe).  This is
+// the only place the library reads its environment; nothing on the launch path does (round 3 had 21 getenv calls there).
+struct Defaults {
+    trt_tuning tuning;
+    trt_scene_options scene;
+};
+const Defaults& defaults() {
+    static const Defaults d = [] {
+        Defaults x;
+        x.tuning = tuning_builtin();
+        x.scene = scene_options_builtin();
+        auto env = [](const char* name) -> const char* { const char* e = getenv(name); return (e && *e) ? e : nullptr; };
+        auto u32 = [&](const char* name, uint32_t& field) { if (const char* e = env(name)) field = (uint32_t)strtoul(e, nullptr, 10); };
+        trt_tuning& t = x.tuning;
+        u32("TRT_STREAM_MINW", t.stream_waves_per_simd); u32("TRT_BIG_THREADS", t.stream_big_threads); u32("TRT_STREAM_BATCH_SPP", t.stream_batch_spp);
+        u32("TRT_RADIANCE_GB", t.radiance_gb); u32("TRT_LEAF_SLOTS", t.leaf_slots); u32("TRT_LDS_LEAF_STACK", t.lds_leaf_stack);
+        u32("TRT_RAY_POOL", t.ray_pool); u32("TRT_STRAGGLERS", t.stragglers); u32("TRT_LDS_STRAGGLERS", t.lds_stragglers);
+        u32("TRT_DUAL_WALK", t.dual_walk); u32("TRT_RUNTIME_WALK", t.runtime_walk); u32("TRT_XCD_REMAP", t.xcd_remap);
+        u32("TRT_MINW", t.mega_waves_per_simd); u32("TRT_MEGA_THREADS", t.mega_threads); u32("TRT_MINW8", t.mega_global_waves8);
+        u32("TRT_WF_MINW", t.wf_waves_per_simd); u32("TRT_WF_SERVE_MIN", t.wf_serve_min);
+        trt_scene_options& o = x.scene;
+        if (const char* e = env("TRT_CULL_PRUNE")) o.cull_prune = (float)atof(e);
+        if (const char* e = env("TRT_FLAT_WALK")) o.flat_walk = atoi(e) ? 1 : 0;
+        if (const char* e = env("TRT_COMPACT_NODES")) o.compact_nodes = atoi(e) ? 1 : 0;
+        u32("TRT_TOP_NODES", o.top_nodes);
+        if (const char* e = env("TRT_SCRATCH_CAP_MB")) o.scratch_cap_bytes = (uint64_t)strtoull(e, nullptr, 10) << 20;
+        return x;
+    }();
+    return d;
+}
 
 int require_device() {
     int n = 0;
@@ -286,11 +317,19 @@ int workspace_acquire(trt_scene* s, int dev, size_t need, hipStream_t stream, Wo
             if (pick->done) (void)hipEventDestroy(pick->done);
             delete pick;
             s->cv.notify_all();
-            if (e == hipErrorOutOfMemory && !dc.ws.empty()) { may_grow = false; continue; }     // out of HBM for another copy: queue behind a running render instead
+            if (e == hipErrorOutOfMemory) {
+                // out of HBM for another copy: queue behind a running render whose buffer is large enough, if there is one; else the caller
+                // may ask for less (TRT_ERR_OOM: enqueue_render halves the samples per launch)
+                bool fits = false;
+                for (Workspace* w : dc.ws) fits = fits || w->bytes >= need;
+                if (fits) { may_grow = false; continue; }
+                return fail(TRT_ERR_OOM, std::string(where) + ": " + hipGetErrorString(e));
+            }
             return fail_hip(e, where);
         }
         pick->busy = false;                                       // (a failed regrow leaves an empty, reusable entry)
         s->cv.notify_all();
+        if (e == hipErrorOutOfMemory) return fail(TRT_ERR_OOM, std::string(where) + ": " + hipGetErrorString(e));
         return fail_hip(e, where);
     }
 }
@@ -401,7 +440,7 @@ void to_camera_dev(const trt_camera& c, CameraDev& d) {
 }
 
 // Validates params against the camera and fills the kernel arguments.  rows = rows the call owns.
-int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs& ra, uint32_t& rows) {
+int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs& ra, uint32_t& rows, trt_tuning& tn) {
     if (cam->width < 2 || cam->height < 2) return fail(TRT_ERR_INVALID_ARG, "camera width and height must be at least 2 (pointgen.rs:41-42 divides by width-1, height-1)");
     if (p->samples_per_pixel == 0) return fail(TRT_ERR_INVALID_ARG, "samples_per_pixel must be positive");
     uint32_t s1 = p->sample_end == 0 ? p->samples_per_pixel : p->sample_end;
@@ -428,13 +467,12 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
         ra.band_rows = p->band_rows; ra.band_stride = p->band_stride; ra.band_offset = p->band_offset;
     }
     ra.rows_local = rows;
-    ra.leaf_slots = 0u;                                    // rt_path.h walk_fast; 0 = the backend's default; scheduling only, any value renders the same frame
-    if (const char* e = getenv("TRT_LEAF_SLOTS")) ra.leaf_slots = (uint32_t)atoi(e);
-    ra.lds_leaf_stack = 1u;
-    if (const char* e = getenv("TRT_LDS_LEAF_STACK")) ra.lds_leaf_stack = (uint32_t)atoi(e);   // 0 off, 1 where it costs no occupancy, 2 always
-    ra.xcd_aware = getenv("TRT_XCD_REMAP") ? 1u : 0u;   // off: contiguous image regions per XCD measured 2x slower (load imbalance)
-    ra.stragglers = 8u;                                    // scheduling only: any value renders the same frame (profiles/r03_stragglers_sweep.txt)
-    if (const char* e = getenv("TRT_STRAGGLERS")) ra.stragglers = (uint32_t)atoi(e);
+    // scheduling (tinyrt.h trt_tuning): the caller's, else the library defaults; scheduling only, any value renders the same frame
+    tn = p->tuning ? *p->tuning : defaults().tuning;
+    ra.leaf_slots = tn.leaf_slots;                         // rt_path.h walk_fast; 0 = the backend's default
+    ra.lds_leaf_stack = tn.lds_leaf_stack;                 // 0 off, 1 where it costs no occupancy, 2 always
+    ra.xcd_aware = tn.xcd_remap ? 1u : 0u;                 // off: contiguous image regions per XCD measured 2x slower (load imbalance)
+    ra.stragglers = tn.stragglers;                         // profiles/r03_stragglers_sweep.txt
     ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;
 }
@@ -442,8 +480,9 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
 int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params* p, float* d_accum, uint64_t* d_counters,
                    hipStream_t stream, uint32_t* rows_out) {
     RenderArgs ra;
+    trt_tuning tn;
     uint32_t rows = 0;
-    int rc = to_render_args(cam, p, ra, rows);
+    int rc = to_render_args(cam, p, ra, rows, tn);
     if (rc != TRT_OK) return rc;
     if (rows_out) *rows_out = rows;
     SceneDev sc;
@@ -460,28 +499,38 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
     const bool wavefront = p->backend == TRT_BACKEND_WAVEFRONT;
     const bool streamed = p->backend == TRT_BACKEND_STREAMED || p->backend == TRT_BACKEND_AUTO;     // fastest on every scene measured
     if (wavefront || streamed) {
-        // Device workspace (wavefront: 72 B of path state per pixel; streamed: 12 B per pixel and sample of a chunk), private
+        // Device workspace (wavefront: 72 B of path state per pixel; streamed: 12 B per pixel and sample of a launch), private
         // to this render until its last kernel has run (workspace_acquire): concurrent renders of one scene are safe.
         int dev = 0;
         TRT_HIP(hipGetDevice(&dev));
-        const size_t need = wavefront ? wavefront_workspace_bytes(cam->width, rows) : streamed_workspace_bytes(cam->width, rows, ra.sample_end - ra.sample_begin);
         Workspace* ws = nullptr;
-        rc = workspace_acquire(s, dev, need, stream, &ws);
+        if (wavefront) {
+            rc = workspace_acquire(s, dev, wavefront_workspace_bytes(cam->width, rows), stream, &ws);
+        } else {
+            // The streamed launch is sized for 288 GB (up to 16 GB of records).  If the device cannot give that much right now - HBM held by
+            // another scene's cached scratch, by the host application, by torch - ask for half the samples per launch, and half again: the
+            // render then runs more, shorter launches (same frame: the fold adds the samples in order whatever the launch boundaries).
+            uint32_t samples = ra.sample_end - ra.sample_begin;
+            const uint32_t full = streamed_chunk_spp(cam->width, rows, tn.radiance_gb);
+            if (samples > full) samples = full;
+            for (;;) {
+                rc = workspace_acquire(s, dev, streamed_workspace_bytes(cam->width, rows, samples, tn.radiance_gb), stream, &ws);
+                if (rc != TRT_ERR_OOM || samples <= 1u) break;
+                samples = (samples + 1u) / 2u;
+            }
+        }
         if (rc != TRT_OK) return rc;
         hipError_t le;
         if (streamed) {
-            le = launch_streamed(sc, cd, ra, ws->ptr, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream);
+            le = launch_streamed(sc, cd, ra, tn, ws->ptr, ws->bytes, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream);
         } else {
-            uint32_t serve_min = 0;
-            if (const char* e = getenv("TRT_WF_SERVE_MIN")) serve_min = (uint32_t)atoi(e);
-            le = launch_wavefront(sc, cd, ra, ws->ptr, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0,
-                                  serve_min, stream);
+            le = launch_wavefront(sc, cd, ra, tn, ws->ptr, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream);
         }
         rc = workspace_release(s, dev, ws, stream);
         if (le != hipSuccess) return fail_hip(le, streamed ? "launch_streamed" : "launch_wavefront");
         return rc;
     }
-    TRT_HIP(launch_megakernel(sc, cd, ra, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));
+    TRT_HIP(launch_megakernel(sc, cd, ra, tn, d_accum, reinterpret_cast<unsigned long long*>(d_counters), p->collect_stats != 0, stream));
     return TRT_OK;
 }
 
@@ -489,6 +538,7 @@ void counters_to_stats(const unsigned long long* c, trt_stats* st) {
     st->samples = c[CTR_SAMPLES]; st->rays = c[CTR_RAYS]; st->node_tests = c[CTR_NODE]; st->sphere_tests = c[CTR_SPHERE];
     st->quad_plane_tests = c[CTR_QUAD_PLANE]; st->quad_inside_tests = c[CTR_QUAD_INSIDE]; st->shades = c[CTR_SHADE];
     for (int i = 0; i < 4; i++) st->wave_trips[i] = c[CTR_W_ROUNDS + i];
+    st->gather_per_band = 0;
 }
 
 }  // namespace
@@ -566,19 +616,25 @@ int trt_world_num_geometries(const trt_world* w) { return w ? (int)w->w.geometri
 int trt_world_num_materials(const trt_world* w) { return w ? (int)w->w.materials.size() : 0; }
 
 // ---- Scene ----
-int trt_scene_create(const trt_world* w, trt_scene** out) {
+void trt_scene_options_default(trt_scene_options* out) { if (out) *out = defaults().scene; }
+void trt_tuning_default(trt_tuning* out) { if (out) *out = defaults().tuning; }
+
+int trt_scene_create_ex(const trt_world* w, const trt_scene_options* options, trt_scene** out) {
     if (!w || !out) return fail(TRT_ERR_INVALID_ARG, "null argument");
     try {
+        const trt_scene_options opt = options ? *options : defaults().scene;
+        if (!(opt.cull_prune > 0.0f && opt.cull_prune <= 1.0f)) return fail(TRT_ERR_INVALID_ARG, "cull_prune must be in (0, 1]");
         trt_scene* s = new trt_scene();
         std::string msg;
-        if (!compile_scene(w->w, s->host, msg)) { delete s; return fail(TRT_ERR_INVALID_ARG, msg); }
-        if (const char* e = getenv("TRT_SCRATCH_CAP_MB")) s->scratch_cap_bytes = (size_t)strtoull(e, nullptr, 10) << 20;
+        if (!compile_scene(w->w, opt, s->host, msg)) { delete s; return fail(TRT_ERR_INVALID_ARG, msg); }
+        s->scratch_cap_bytes = (size_t)opt.scratch_cap_bytes;
         *out = s;
     } catch (const std::bad_alloc&) {
         return fail(TRT_ERR_OOM, "out of memory");
     }
     return TRT_OK;
 }
+int trt_scene_create(const trt_world* w, trt_scene** out) { return trt_scene_create_ex(w, nullptr, out); }
 // Frees every idle cached device buffer of the scene (workspaces whose render has finished, idle contexts' frames); the
 // packed scene stays.  Safe while renders of the scene run: what they own is skipped.
 int trt_scene_trim(trt_scene* s) {
@@ -679,8 +735,9 @@ int trt_render(trt_scene* s, const trt_camera* cam, const trt_render_params* p, 
     int rc = require_device();
     if (rc != TRT_OK) return rc;
     RenderArgs probe;
+    trt_tuning probe_tn;
     uint32_t rows = 0;
-    rc = to_render_args(cam, p, probe, rows);
+    rc = to_render_args(cam, p, probe, rows, probe_tn);
     if (rc != TRT_OK) return rc;
     const size_t bytes = (size_t)rows * cam->width * 3 * sizeof(float);
     int dev = 0;
@@ -737,6 +794,7 @@ struct MultiShard {
     int device = 0;
     uint32_t rank = 0, rows_local = 0;
     bool peer_ok = true;                      // the gather may address the destination device directly
+    bool per_band = false;                    // the gather went band by band (no peer access, or the strided peer copy was refused)
     int rc = TRT_OK;
     std::string error;
     unsigned long long ctr[CTR_COUNT] = {0};
@@ -841,7 +899,7 @@ void render_shard(trt_scene* s, const trt_camera* cam, const trt_render_params* 
     sh->rc = enqueue_render(s, cam, &q, c->d_accum, reinterpret_cast<uint64_t*>(c->d_ctr), c->stream, nullptr);
     if (sh->rc != TRT_OK) { sh->error = g_last_error; finish(); return; }
     TRT_HIP_S(hipEventRecord(c->ev1, c->stream));
-    TRT_HIP_S(copy_bands(pl, local, frame, true, sh->device, dst_device, sh->peer_ok, c->stream));                       // the gather
+    TRT_HIP_S(copy_bands(pl, local, frame, true, sh->device, dst_device, sh->peer_ok, c->stream, &sh->per_band));        // the gather
     TRT_HIP_S(hipMemcpyAsync(sh->ctr, c->d_ctr, sizeof(sh->ctr), hipMemcpyDeviceToHost, c->stream));
     TRT_HIP_S(hipStreamSynchronize(c->stream));
     TRT_HIP_S(hipEventElapsedTime(&sh->ms, c->ev0, c->ev1));
@@ -868,8 +926,9 @@ int render_multi(trt_scene* s, const trt_camera* cam, const trt_render_params* p
     }
     {   // validate once on the calling thread, so argument errors do not depend on a device
         RenderArgs probe;
+        trt_tuning probe_tn;
         uint32_t rows = 0;
-        rc = to_render_args(cam, p, probe, rows);
+        rc = to_render_args(cam, p, probe, rows, probe_tn);
         if (rc != TRT_OK) return rc;
     }
     int prev = 0;
@@ -905,12 +964,14 @@ int render_multi(trt_scene* s, const trt_camera* cam, const trt_render_params* p
     (void)hipSetDevice(prev);
     unsigned long long total[CTR_COUNT] = {0};
     float ms = 0.0f;
+    uint64_t per_band = 0;
     for (const MultiShard& sh : shards) {
         if (sh.rc != TRT_OK) return fail(sh.rc, "device " + std::to_string(sh.device) + ": " + sh.error);
         for (int k = 0; k < CTR_COUNT; k++) total[k] += sh.ctr[k];
         if (sh.ms > ms) ms = sh.ms;
+        per_band += sh.per_band ? 1u : 0u;
     }
-    if (stats) { counters_to_stats(total, stats); stats->kernel_ms = ms; }      // kernel_ms: the slowest device's
+    if (stats) { counters_to_stats(total, stats); stats->kernel_ms = ms; stats->gather_per_band = per_band; }      // kernel_ms: the slowest device's
     return TRT_OK;
 }
 
@@ -1011,16 +1072,17 @@ int trt_sample_batch(trt_scene* s, const trt_sample_point* in, uint32_t n, trt_s
     return TRT_OK;
 }
 
-uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows) { return streamed_chunk_spp(width, rows); }
+uint32_t trt_streamed_chunk_spp(uint32_t width, uint32_t rows) { return streamed_chunk_spp(width, rows, defaults().tuning.radiance_gb); }
 
 // How the streamed backend would launch this render (host arithmetic only: works without a GPU).
 int trt_streamed_launch_plan(const trt_scene* s, const trt_camera* cam, const trt_render_params* p, trt_launch_plan* out) {
     if (!s || !cam || !p || !out) return fail(TRT_ERR_INVALID_ARG, "null argument");
     RenderArgs ra;
+    trt_tuning tn;
     uint32_t rows = 0;
-    int rc = to_render_args(cam, p, ra, rows);
+    int rc = to_render_args(cam, p, ra, rows, tn);
     if (rc != TRT_OK) return rc;
-    const StreamLaunchPlan pl = streamed_launch_plan(s->host.layout, ra, p->collect_stats != 0);
+    const StreamLaunchPlan pl = streamed_launch_plan(s->host.layout, ra, tn, p->collect_stats != 0);
     memset(out, 0, sizeof(*out));
     out->scene_mode = (uint32_t)pl.mode;
     out->threads_per_workgroup = (uint32_t)pl.threads;
@@ -1039,8 +1101,9 @@ int trt_streamed_launch_plan(const trt_scene* s, const trt_camera* cam, const tr
     out->kernel_walk = (uint32_t)pl.kernel_walk;
     out->kernel_ray_pool = pl.kernel_pool ? 1u : 0u;
     out->kernel_counting = pl.kernel_stats ? 1u : 0u;
-    out->chunk_spp = streamed_chunk_spp(cam->width, rows);
-    out->workspace_bytes = streamed_workspace_bytes(cam->width, rows, ra.sample_end - ra.sample_begin);
+    out->chunk_spp = streamed_chunk_spp(cam->width, rows, tn.radiance_gb);
+    out->dual_walk = pl.dual ? 1u : 0u;
+    out->workspace_bytes = streamed_workspace_bytes(cam->width, rows, ra.sample_end - ra.sample_begin, tn.radiance_gb);
     return TRT_OK;
 }
 
@@ -1085,11 +1148,12 @@ int trt_kernel_timing_end(double* total_ms, uint32_t* launches) {
 const char* trt_dominant_kernel(const trt_scene* s, const trt_camera* cam, const trt_render_params* p) {
     if (!s || !cam || !p) return "";
     RenderArgs ra;
+    trt_tuning tn;
     uint32_t rows = 0;
-    if (to_render_args(cam, p, ra, rows) != TRT_OK) return "";
+    if (to_render_args(cam, p, ra, rows, tn) != TRT_OK) return "";
     if (p->backend == TRT_BACKEND_WAVEFRONT) return "trt::wavefront_kernel";
     if (p->backend == TRT_BACKEND_MEGAKERNEL) return "trt::megakernel";
-    return streamed_kernel_name(s->host.layout, ra);
+    return streamed_kernel_name(s->host.layout, ra, tn);
 }
 
 // ---- Imager finalisation ----

@@ -35,6 +35,28 @@ struct RenderArgs {
                                  // (they carry their walk into the next round); 0 = every walk runs to its end (rt_path.h walk_compact)
 };
 
+// The built-in scheduling defaults (tinyrt.h trt_tuning; each a measured optimum, DESIGN.md "Tuning").  They live in THIS header -
+// which bench.py's kernel-source digest covers - because they decide which kernel runs and how: a stored PMC profile is valid
+// for one set of defaults only.
+inline trt_tuning tuning_builtin() {
+    trt_tuning t{};
+    t.stream_waves_per_simd = 0;      // by scene: 6 (LDS), 8 (global memory)
+    t.stream_big_threads = 0;         // auto: 768 where the LDS leaf stack then fits, else 512
+    t.stream_batch_spp = 8;
+    t.radiance_gb = 16;
+    t.leaf_slots = 0;                 // by launch plan
+    t.lds_leaf_stack = 1;
+    t.ray_pool = 1;
+    t.stragglers = 8;                 // profiles/r03_stragglers_sweep.txt
+    t.lds_stragglers = 8;
+    t.dual_walk = 0;
+    t.runtime_walk = 0;
+    t.xcd_remap = 0;
+    t.mega_waves_per_simd = 0; t.mega_threads = 0; t.mega_global_waves8 = 0;
+    t.wf_waves_per_simd = 0; t.wf_serve_min = 0;
+    return t;
+}
+
 // trt-rng v1 per-launch key: mix32(seed + golden ratio), evaluated once on the host.
 inline uint32_t rng_seed_key(uint32_t seed) {
     uint32_t x = seed + 0x9E3779B9u;
@@ -58,7 +80,7 @@ inline uint32_t scene_lds_bytes(const SceneLayout& L) { int m = scene_mode(L); r
 void timing_mark(hipStream_t stream, bool begin);
 
 // Megakernel: whole bounce loop for every pixel of the local rows in one launch.
-hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
+hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, const trt_tuning& tn, float* d_accum,
                              unsigned long long* d_counters, bool stats, hipStream_t stream);
 
 // Wavefront backend (wavefront.hip): path state lives SoA in a caller-provided HBM workspace.
@@ -70,13 +92,15 @@ struct WfState {
     uint2* rng;     // trt-rng v1 stream state
 };
 size_t wavefront_workspace_bytes(uint32_t width, uint32_t rows);
-hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
-                            unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream);
+hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, const trt_tuning& tn, void* workspace, float* d_accum,
+                            unsigned long long* d_counters, bool stats, hipStream_t stream);
 
 // Streamed backend (streamed.hip): samples are work items; radiances go to an HBM buffer and are folded in order.
-uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows);   // samples per pixel per sample/fold launch pair (bounds the radiance buffer)
-size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples);   // samples = sample_end - sample_begin of the render
-const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra);
+uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows, uint32_t radiance_gb);   // samples per pixel per tracing / fold launch pair (bounds the radiance buffer)
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples, uint32_t radiance_gb);   // samples = sample_end - sample_begin of the render
+// Samples per pixel a workspace of `bytes` holds for this image (what launch_streamed may trace per launch with the scratch it was granted).
+uint32_t streamed_chunk_that_fits(uint32_t width, uint32_t rows, size_t bytes);
+const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra, const trt_tuning& tn);
 // How launch_streamed runs a scene with these settings (streamed.hip; also what trt_streamed_launch_plan reports).  The
 // kernel's view of its dynamic LDS - scene copy | leaf stack (threads x slots x 8 B) | ray pool (36 B per lane) - is fixed
 // here and nowhere else; launch_streamed refuses a plan whose parts do not add up (hipErrorInvalidConfiguration).
@@ -84,6 +108,7 @@ struct StreamLaunchPlan {
     int mode, threads, waves_per_simd;      // scene mode, lanes per workgroup, waves per SIMD the grid is sized for
     uint32_t wg_per_cu, slots;              // resident workgroups per CU; postponed-leaf slots per lane
     bool lds_stack, flat, compact, pool, specialised;
+    bool dual;                              // two paths per lane (stream_dual_kernel): two leaf stacks per lane
     int walk;                               // WALK_* the kernel will run
     size_t lds_bytes, scene_lds_bytes;      // dynamic LDS per workgroup; the scene copy's share of it
     const void* kernel;                     // the instantiation (nullptr: none - a bug, launch_streamed fails)
@@ -91,9 +116,10 @@ struct StreamLaunchPlan {
     bool kernel_pool, kernel_stats;
     const char* kernel_name;
 };
-StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra, bool stats);
-hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
-                           unsigned long long* d_counters, bool stats, hipStream_t stream);
+StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra, const trt_tuning& tn, bool stats);
+// `workspace_bytes`: what the caller was granted (at least streamed_workspace_bytes for one sample): the launches are sized to it.
+hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, const trt_tuning& tn, void* workspace, size_t workspace_bytes,
+                           float* d_accum, unsigned long long* d_counters, bool stats, hipStream_t stream);
 
 // Sampler plug-in form: n caller-supplied rays.
 // Imager finalisation on buffers in HBM (kernels.hip).

@@ -154,7 +154,7 @@ static hipError_t launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_
     return le;
 }
 
-hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, float* d_accum,
+hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, const trt_tuning& tn, float* d_accum,
                              unsigned long long* d_counters, bool stats, hipStream_t stream) {
     // Workgroup size and register budget.  The kernel wants 98 VGPRs (4 waves/SIMD); capping it by launch bound buys
     // occupancy for a few spilled dwords.  Measured on Cornell 2048^2 (Gray/s): 4 waves 20.7, 5: 22.5, 6: 23.3, 7: 23.9,
@@ -164,8 +164,8 @@ hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const Ren
     const int mode = scene_mode(sc.L);
     int threads = (mode == MODE_LDS && sc.L.hot_bytes > 20u * 1024u) ? 512 : 256;
     int w = mode != MODE_LDS ? 1 : (threads == 512 ? 6 : 7);
-    if (const char* e = getenv("TRT_MEGA_THREADS")) threads = (mode == MODE_LDS && atoi(e) == 512) ? 512 : 256;   // only MODE_LDS has 512-lane instances
-    if (const char* e = getenv("TRT_MINW")) w = atoi(e);
+    if (tn.mega_threads) threads = (mode == MODE_LDS && tn.mega_threads == 512u) ? 512 : 256;   // only MODE_LDS has 512-lane instances
+    if (tn.mega_waves_per_simd) w = (int)tn.mega_waves_per_simd;
     const uint32_t tile_h = (uint32_t)threads / 16u;
     const uint32_t tiles_x = (cam.width + kTileW - 1) / kTileW, tiles_y = (ra.rows_local + tile_h - 1) / tile_h;
     if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
@@ -183,7 +183,7 @@ hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const Ren
             return stats ? go(megakernel<MODE_LDS, true, 5>) : go(megakernel<MODE_LDS, false, 5>);
         case MODE_HYBRID: return stats ? go(megakernel<MODE_HYBRID, true>) : go(megakernel<MODE_HYBRID, false>);
         default:
-            if (getenv("TRT_MINW8")) return stats ? go(megakernel<MODE_GLOBAL, true, 8>) : go(megakernel<MODE_GLOBAL, false, 8>);
+            if (tn.mega_global_waves8) return stats ? go(megakernel<MODE_GLOBAL, true, 8>) : go(megakernel<MODE_GLOBAL, false, 8>);
             return stats ? go(megakernel<MODE_GLOBAL, true>) : go(megakernel<MODE_GLOBAL, false>);
     }
 }

@@ -690,6 +690,130 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Two walks per lane (round 4).  walk_compact keeps ONE 16-byte load in flight per wave, and a trip waits for it: at eight waves per
+// SIMD that is eight loads in flight per SIMD, 42 % of all wave-cycles parked in s_waitcnt (profiles/r03_grid100k_pmc.json) and the
+// vector unit issuing 0.42 of its slots.  Eight is the most waves a SIMD holds, so more loads in flight have to come from inside a
+// wave: every lane walks TWO rays, A and B, each exactly as walk_compact walks one (same node order, same tests, same t_best
+// evolution - the two walks share nothing but the instruction stream), and a trip requests both rays' nodes before it waits for the
+// first.  box_loop_compact2 is box_loop_compact's body twice between the two requests and the two waits; the registers it works in
+// (v44-v57) are shared by the two halves, the loads land in v[44:47] and v[48:51].
+// A walk that is not active (no ray in that slot, or its walk is over) comes in with i == n; a slot's lanes are masked by an SGPR
+// pair recomputed every trip (i < n && top != limit), and the loop ends when at most `few` RAYS of the wave (both slots counted) can
+// still step - 0 when the last one is done.  A VMEM instruction issued with exec == 0 moves no data but keeps vmcnt in step, so both
+// requests are always issued and vmcnt(1) / vmcnt(0) mean "A's node" / "B's node" whatever the masks; a half whose mask is empty
+// skips its arithmetic (s_cbranch_execz).
+#define TRT_COMPACT_STEP(D0, D1, D2, D3, I, TOP)                                                                                              \
+        "v_cvt_f32_f16_e32 v52, " D0 "\n"                                                                 /* lo.x */                        \
+        "v_cvt_f32_f16_sdwa " D0 ", " D0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* lo.y */                        \
+        "v_cvt_f32_f16_e32 v53, " D1 "\n"                                                                 /* lo.z */                        \
+        "v_cvt_f32_f16_sdwa " D1 ", " D1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* hi.x */                        \
+        "v_cvt_f32_f16_e32 v54, " D2 "\n"                                                                 /* hi.y */                        \
+        "v_cvt_f32_f16_sdwa " D2 ", " D2 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* hi.z */                        \
+        "v_sub_f32_e32 v52, v52, %[ox" I "]\n v_sub_f32_e32 " D1 ", " D1 ", %[ox" I "]\n v_sub_f32_e32 " D0 ", " D0 ", %[oy" I "]\n"        \
+        "v_sub_f32_e32 v54, v54, %[oy" I "]\n v_sub_f32_e32 v53, v53, %[oz" I "]\n v_sub_f32_e32 " D2 ", " D2 ", %[oz" I "]\n"              \
+        "v_mul_f32_e32 v52, v52, %[ix" I "]\n v_mul_f32_e32 " D1 ", " D1 ", %[ix" I "]\n v_mul_f32_e32 " D0 ", " D0 ", %[iy" I "]\n"        \
+        "v_mul_f32_e32 v54, v54, %[iy" I "]\n v_mul_f32_e32 v53, v53, %[iz" I "]\n v_mul_f32_e32 " D2 ", " D2 ", %[iz" I "]\n"              \
+        "v_min_f32_e32 v55, v52, " D1 "\n v_max_f32_e32 v52, v52, " D1 "\n v_min_f32_e32 v56, " D0 ", v54\n"                               \
+        "v_max_f32_e32 " D0 ", " D0 ", v54\n v_max_f32_e32 v55, v55, v56\n v_min_f32_e32 v56, v53, " D2 "\n"                               \
+        "v_max_f32_e32 v53, v53, " D2 "\n v_min_f32_e32 v52, v52, " D0 "\n v_max3_f32 v55, v55, v56, %[tmin]\n"      /* start */           \
+        "v_min3_f32 v52, %[tb" I "], v52, v53\n"                                                                      /* end */             \
+        "v_cmp_nle_f32_e32 vcc, v52, v55\n"                                                         /* pass = !(end <= start) */            \
+        "v_cmp_gt_i32_e64 %[m0], 0, " D3 "\n"                                                       /* leaf: sign bit of the link */        \
+        "s_or_b64 %[m1], vcc, %[m0]\n"                                                                                                     \
+        "v_add_u32_e32 v56, 1, %[i" I "]\n"                                                                                                \
+        "v_cndmask_b32_e64 %[i" I "], " D3 ", v56, %[m1]\n"                                         /* next node, or the skip link */       \
+        "s_and_b64 %[m1], vcc, %[m0]\n"                                                             /* a leaf whose coarse box passes: */   \
+        "s_and_b64 exec, exec, %[m1]\n"                                                                                                    \
+        "v_and_b32_e32 v54, 0x7fffffff, " D3 "\n"                                                                                          \
+        "ds_write2_b32 %[top" I "], v54, v55 offset1:1\n"                                           /*   (leaf number, coarse start) */     \
+        "v_add_u32_e32 %[top" I "], 0x200, %[top" I "]\n"
+
+TRT_DEV void box_loop_compact2(uint32_t& iA, uint32_t& iB, const V3& oA, const V3& oB, const V3& invA, const V3& invB, float tbA, float tbB,
+                               const uint4* __restrict__ nodes16, float2* stkA, float2* stkB, uint32_t slots, float2*& topA_out, float2*& topB_out,
+                               uint32_t n, uint32_t few) {
+    const uint32_t stkA_off = lds_offset(stkA), stkB_off = lds_offset(stkB);
+    uint32_t topA = stkA_off, topB = stkB_off;
+    const uint32_t limA = stkA_off + 512u * slots, limB = stkB_off + 512u * slots;
+    unsigned long long saved, mA, mB, m0, m1;
+    uint32_t cnt, cnt2;
+    asm volatile(
+        "s_mov_b64 %[sv], exec\n"
+        "1:\n"
+        "v_cmp_gt_u32_e32 vcc, %[n], %[iA]\n"
+        "v_cmp_ne_u32_e64 %[m0], %[topA], %[limA]\n"
+        "s_and_b64 %[mA], vcc, %[m0]\n"
+        "v_cmp_gt_u32_e32 vcc, %[n], %[iB]\n"
+        "v_cmp_ne_u32_e64 %[m0], %[topB], %[limB]\n"
+        "s_and_b64 %[mB], vcc, %[m0]\n"
+        "s_bcnt1_i32_b64 %[cnt], %[mA]\n"
+        "s_bcnt1_i32_b64 %[cnt2], %[mB]\n"
+        "s_add_u32 %[cnt], %[cnt], %[cnt2]\n"
+        "s_cmp_le_u32 %[cnt], %[few]\n"                       // at most `few` rays can still step (0: none): leave
+        "s_cbranch_scc1 2f\n"
+        "s_mov_b64 exec, %[mA]\n"
+        "v_lshlrev_b32_e32 v52, 4, %[iA]\n"
+        "global_load_dwordx4 v[44:47], v52, %[nodes]\n"
+        "s_mov_b64 exec, %[mB]\n"
+        "v_lshlrev_b32_e32 v53, 4, %[iB]\n"
+        "global_load_dwordx4 v[48:51], v53, %[nodes]\n"
+        "s_mov_b64 exec, %[mA]\n"
+        "s_waitcnt vmcnt(1)\n"
+        "s_cbranch_execz 3f\n"
+        TRT_COMPACT_STEP("v44", "v45", "v46", "v47", "A", "A")
+        "3:\n"
+        "s_mov_b64 exec, %[mB]\n"
+        "s_waitcnt vmcnt(0)\n"
+        "s_cbranch_execz 4f\n"
+        TRT_COMPACT_STEP("v48", "v49", "v50", "v51", "B", "B")
+        "4:\n"
+        "s_mov_b64 exec, %[sv]\n"
+        "s_branch 1b\n"
+        "2:\n"
+        : [iA] "+v"(iA), [iB] "+v"(iB), [topA] "+v"(topA), [topB] "+v"(topB), [sv] "=&s"(saved), [mA] "=&s"(mA), [mB] "=&s"(mB), [m0] "=&s"(m0),
+          [m1] "=&s"(m1), [cnt] "=&s"(cnt), [cnt2] "=&s"(cnt2)
+        : [n] "s"(n), [few] "s"(few), [nodes] "s"(nodes16), [limA] "v"(limA), [limB] "v"(limB), [oxA] "v"(oA.x), [oyA] "v"(oA.y), [ozA] "v"(oA.z),
+          [ixA] "v"(invA.x), [iyA] "v"(invA.y), [izA] "v"(invA.z), [tbA] "v"(tbA), [oxB] "v"(oB.x), [oyB] "v"(oB.y), [ozB] "v"(oB.z), [ixB] "v"(invB.x),
+          [iyB] "v"(invB.y), [izB] "v"(invB.z), [tbB] "v"(tbB), [tmin] "s"(kTMin)
+        : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
+    topA_out = stkA + ((topA - stkA_off) >> 3);
+    topB_out = stkB + ((topB - stkB_off) >> 3);
+}
+
+// The exact-box re-test and the primitive test of a postponed leaf of walk_compact (its leaf_phase body).
+template <int MODE, bool STATS>
+TRT_DEV void compact_leaf_test(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf_list, const Ray& ray, Trav& tr, uint32_t leaf, Counters<STATS>& ctr) {
+    const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
+    if constexpr (STATS) ctr.node++;
+    if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
+}
+
+// Both walks of a lane, resumable like walk_compact: returns with doneA / doneB = "that slot's walk is complete" once at most `few` rays
+// of the wave (both slots) are still walking; a slot that is not `act` is left alone.  `entered` = rays that came in.
+template <int MODE>
+TRT_DEV void walk_compact2(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list, const Ray& rayA,
+                           Trav& trA, bool actA, const Ray& rayB, Trav& trB, bool actB, Counters<false>& ctr, float2* stkA, float2* stkB,
+                           uint32_t slots, uint32_t stragglers, uint32_t entered, bool& doneA, bool& doneB) {
+    const uint32_t n = sc.L.n_cull_nodes;
+    // the rare walks (a ray whose slab arithmetic can produce NaN): reference tree, to the end, one slot after the other
+    if (actA && trA.ref) { closest_hit_ref<MODE, false>(sc, rayA, trA, ctr); trA.i = n; }
+    if (actB && trB.ref) { closest_hit_ref<MODE, false>(sc, rayB, trB, ctr); trB.i = n; }
+    uint32_t iA = actA ? trA.i : n, iB = actB ? trB.i : n;
+    const uint32_t few = stragglers < entered ? stragglers : entered - 1u;             // see walk_fast_lds
+    for (;;) {
+        float2 *topA, *topB;
+        box_loop_compact2(iA, iB, rayA.o, rayB.o, trA.inv, trB.inv, trA.t_best, trB.t_best, nodes16, stkA, stkB, slots, topA, topB, n, few);
+        TRT_CLK(ctr, 1);
+        if (topA != stkA) leaf_phase<MODE, false>(stkA, topA, trA, ctr, [&](uint32_t leaf) { compact_leaf_test<MODE, false>(sc, leaf_list, rayA, trA, leaf, ctr); });
+        if (topB != stkB) leaf_phase<MODE, false>(stkB, topB, trB, ctr, [&](uint32_t leaf) { compact_leaf_test<MODE, false>(sc, leaf_list, rayB, trB, leaf, ctr); });
+        TRT_CLK(ctr, 2);
+        const uint32_t still = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(iA < n)) + (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(iB < n));
+        if (still <= few) break;
+    }
+    trA.i = iA; trB.i = iB;
+    doneA = iA >= n; doneB = iB >= n;
+}
+
 constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)
 
 // Which walk a kernel instantiation runs.  WALK_RUNTIME picks by the launch arguments (every knob combination; counting
@@ -862,6 +986,15 @@ TRT_DEV void path_begin(Path& p, const CameraDev& cam, const RenderArgs& ra, uin
     p.color = v3(0.0f, 0.0f, 0.0f);
     p.atten = v3(1.0f, 1.0f, 1.0f);
     p.remain = ra.max_bounces;
+}
+
+// A radiance record of the streamed backend: 12 bytes at a 4-byte-aligned address, moved as ONE vector-memory instruction
+// (global_store_dwordx3 / global_load_dwordx3: assigning the packed struct is what makes the compiler emit it - three float stores
+// through a float* stay three instructions, which is what rounds 1-3 shipped: 3 VMEM writes per finished path and partial-sector
+// writes that the L2 had to merge, WRITE_SIZE 1.6-4.3x the records' bytes in profiles/r03_*_pmc.json).
+struct __attribute__((packed, aligned(4))) Radiance { float r, g, b; };
+TRT_DEV void radiance_store(float* __restrict__ colors, uint32_t slot, const V3& c) {
+    *reinterpret_cast<Radiance*>(colors + 3ull * slot) = Radiance{c.x, c.y, c.z};
 }
 
 // Workgroup -> tile index.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, each XCD

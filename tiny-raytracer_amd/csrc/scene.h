@@ -106,7 +106,10 @@ struct SceneHost {
 };
 
 // Builds the reference's BVH over `w`, derives the culling tree and packs both.  Returns false (with msg) on an empty world.
-bool compile_scene(const World& w, SceneHost& out, std::string& msg);
+// `opt`: trt_scene_options (tinyrt.h) - placement only, every value packs a scene that renders the same frames.
+bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out, std::string& msg);
+// The built-in defaults (cull_prune 0.5, flat_walk / compact_nodes automatic, no top-level cache, 32 GiB idle scratch).
+trt_scene_options scene_options_builtin();
 
 // Camera::new (camera.rs:17-56)
 void camera_init(trt_camera& out, float focus_distance, float defocus_angle_deg, trt_vec3 position, trt_vec3 look_at,

@@ -157,16 +157,14 @@ uint16_t f32_to_f16_dir(float x, bool up) {
 }
 
 struct CullBuilder {
-    double kPrune = 0.5;                     // measured best on MI355X (round 3, profiles/r03_defaults_sweep.txt: random-spheres 0.4-0.5 beat 0.7 by 3 %, the
-                                             // 100 k-sphere scene is flat from 0.3 to 0.7); env TRT_CULL_PRUNE overrides (tuning; any value gives the same hits)
+    double kPrune;                           // trt_scene_options.cull_prune: 0.5 measured best on MI355X (round 3, profiles/r03_defaults_sweep.txt: random-spheres
+                                             // 0.4-0.5 beat 0.7 by 3 %, the 100 k-sphere scene is flat from 0.3 to 0.7); any value gives the same hits
     const std::vector<Box>& leaf_box;        // leaf k of the reference tree, in left-first order
     std::vector<Box> node_box;
     std::vector<int32_t> node_leaf;          // leaf sequence number or -1
     std::vector<int32_t> node_skip;
 
-    explicit CullBuilder(const std::vector<Box>& lb) : leaf_box(lb) {
-        if (const char* e = getenv("TRT_CULL_PRUNE")) kPrune = atof(e);
-    }
+    CullBuilder(const std::vector<Box>& lb, double prune) : kPrune(prune), leaf_box(lb) {}
 
     struct Frame { uint32_t a, b; double parent_sa; int32_t node; bool close; };
 
@@ -227,7 +225,17 @@ void dump_tree(NodeDump& d, const std::vector<Box>& boxes, const std::vector<int
 
 }  // namespace
 
-bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
+trt_scene_options scene_options_builtin() {
+    trt_scene_options o{};
+    o.cull_prune = 0.5f;
+    o.flat_walk = -1;
+    o.compact_nodes = -1;
+    o.top_nodes = kTopNodesMax;
+    o.scratch_cap_bytes = (uint64_t)32 << 30;      // one full-size streamed workspace is up to 16 GB: the cap must hold it, or every render re-allocates
+    return o;
+}
+
+bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out, std::string& msg) {
     const size_t ng = w.geometries.size();
     if (ng == 0) { msg = "world has no geometry"; return false; }
     if (ng > PRIM_INDEX_MASK) { msg = "too many geometries"; return false; }
@@ -286,7 +294,7 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     for (uint32_t i = 0; i < nn; i++) {
         if (b.node_prim[i] >= 0) { leaf_box.push_back(b.node_box[i]); leaf_geo.push_back(b.node_prim[i]); }
     }
-    CullBuilder cb(leaf_box);
+    CullBuilder cb(leaf_box, opt.cull_prune > 0.0f ? (double)opt.cull_prune : 0.5);
     cb.build();
     const uint32_t nc = (uint32_t)cb.node_box.size();
     std::vector<int32_t> cull_prim_geo(nc);
@@ -309,7 +317,7 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     L.blob_bytes = L.hot_bytes + 32u * nn + 32u * (L.n_leaves + kLeafListPad);     // the leaf list is followed by kLeafListPad copies of its last entry
     L.off_compact = 0u;
     bool want_compact = L.hot_bytes > kLdsSceneMaxBytes;                      // scenes walked from global memory
-    if (const char* e = getenv("TRT_COMPACT_NODES")) want_compact = atoi(e) != 0;             // tuning / tests; same frames either way
+    if (opt.compact_nodes >= 0) want_compact = opt.compact_nodes != 0;                        // tuning / tests; same frames either way
     if (want_compact) {
         L.off_compact = L.blob_bytes / 16u;
         L.blob_bytes += 16u * nc;
@@ -331,7 +339,7 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
     }
     L.lazy_color = lazy ? 1u : 0u;
     L.flat_walk = L.n_leaves <= kFlatWalkMaxLeaves ? 1u : 0u;
-    if (const char* e = getenv("TRT_FLAT_WALK")) L.flat_walk = atoi(e) ? 1u : 0u;            // tuning / tests; same frames either way
+    if (opt.flat_walk >= 0) L.flat_walk = opt.flat_walk ? 1u : 0u;                           // tuning / tests; same frames either way
 
     out.blob.assign(L.blob_bytes, 0);
     F4* f4 = reinterpret_cast<F4*>(out.blob.data());
@@ -374,8 +382,8 @@ bool compile_scene(const World& w, SceneHost& out, std::string& msg) {
         }
         std::vector<uint32_t> per_level(max_d + 1, 0);
         for (uint32_t i = 0; i < nc; i++) per_level[depth[i]]++;
-        uint32_t top_levels = 0, total = 0, cap = kTopNodesMax;
-        if (const char* e = getenv("TRT_TOP_NODES")) cap = (uint32_t)atoi(e);        // tuning knob (placement only: results never change)
+        uint32_t top_levels = 0, total = 0;
+        const uint32_t cap = opt.top_nodes;                                          // tuning knob (placement only: results never change)
         while (top_levels <= max_d && total + per_level[top_levels] <= cap) { total += per_level[top_levels]; top_levels++; }
         n_top = total;
         std::vector<uint32_t> next_in_level(top_levels, 0);

@@ -20,15 +20,12 @@
 // two launches per chunk of samples (sized to a radiance buffer of at most 16 GB: streamed_chunk_spp) instead of one.  stream_sample_kernel keeps the
 // primary-ray stock of kernels.hip (items are taken ahead); stream_pool_kernel, used for small LDS scenes, generates the
 // primary rays of a whole wave at once into an LDS pool.
-#include <stdlib.h>
-
 #include "kernels.h"
 #include "rt_path.h"
 
 namespace trt {
 
 constexpr uint32_t kBatchSpp = 8;            // samples per pixel in one batch
-constexpr uint32_t kLdsStragglers = 8;       // LDS tree walk: lanes that may carry an unfinished walk into the next round (TRT_LDS_STRAGGLERS; 0 = none)
 
 TRT_DEV uint32_t st_rank(uint64_t mask) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -134,8 +131,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                 walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
                 if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
-                        float* c = colors + 3ull * out_idx;
-                        c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                        radiance_store(colors, out_idx, p.color);
                         has_path = false;
                     }
                 }
@@ -144,8 +140,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                 float t;
                 const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16);
                 if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
-                    float* c = colors + 3ull * out_idx;
-                    c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                    radiance_store(colors, out_idx, p.color);
                     has_path = false;
                 }
             }
@@ -273,8 +268,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                 walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
                 if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
-                        float* c = colors + 3ull * out_idx;
-                        c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                        radiance_store(colors, out_idx, p.color);
                         has_path = false;
                     }
                 }
@@ -283,8 +277,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                 float t;
                 const uint32_t prim = closest_hit<MODE, STATS, WALK>(sc, p.ray, STATS && ra.ref_tree != 0u, t, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16);
                 if (shade_hit<MODE, STATS, LAZY>(sc, p, prim, t, background, ctr)) {
-                    float* c = colors + 3ull * out_idx;
-                    c[0] = p.color.x; c[1] = p.color.y; c[2] = p.color.z;
+                    radiance_store(colors, out_idx, p.color);
                     has_path = false;
                 }
             }
@@ -292,6 +285,137 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
         TRT_CLK(ctr, 3);
     }
     flush_counters<STATS>(counters, n_samples, n_rays, ctr);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The pool kernel for scenes in global memory with TWO paths per lane (rt_path.h walk_compact2): slot A and slot B of a lane are two
+// independent paths - each takes its primary rays from the wave's pool, walks, is shaded and stores its radiance exactly as the one
+// path of stream_pool_kernel does - and a round steps both walks in one loop that keeps two node loads in flight per wave.  LDS per
+// wave: two postponed-leaf stacks (slot A's, then slot B's) and the ray pool.  Which lane and which slot traces which sample
+// changes; no sample's radiance does (RNG keyed by pixel and sample, radiance stored per sample, folded in order).
+// ------------------------------------------------------------------------------------------------------------------
+struct DualSlot {
+    Path p;
+    uint32_t out_idx = 0;
+    bool has_path = false;
+    bool walking = false;          // the slot's walk is parked in its leaf stack
+};
+
+template <int MINW, int THREADS = 256>
+__global__ __launch_bounds__(THREADS, MINW) void stream_dual_kernel(SceneDev scd, CameraDev cam, RenderArgs ra,
+                                                                           float* __restrict__ colors,
+                                                                           uint32_t* __restrict__ batch_counter,
+                                                                           unsigned long long* __restrict__ counters,
+                                                                           uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp,
+                                                                           const float4* __restrict__ leaf_list,
+                                                                           const uint4* __restrict__ nodes16) {
+    constexpr int MODE = MODE_GLOBAL;
+    const SceneAcc<MODE> sc{scd.blob, scd.L};
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
+    const uint32_t n_spp = ra.sample_end - ra.sample_begin;
+    const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
+    char* const lds_tail = reinterpret_cast<char*>(g_lds);
+    float2* const stkA = reinterpret_cast<float2*>(lds_tail) + (2u * wave) * (64u * ra.leaf_slots) + lane;
+    float2* const stkB = stkA + 64u * ra.leaf_slots;
+    uint32_t* const pool = reinterpret_cast<uint32_t*>(lds_tail + (size_t)THREADS * 2u * ra.leaf_slots * sizeof(float2)) + wave * (64u * kPoolDwords);
+
+    uint32_t tile_x0 = 0, tile_row0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // wave-uniform work cursor
+    uint32_t pool_head = 0, pool_count = 0;                                            // wave-uniform
+    bool exhausted = false;
+    uint32_t n_samples = 0, n_rays = 0;
+    Counters<false> ctr;
+    DualSlot A, B;
+    A.p.remain = 0u; B.p.remain = 0u;
+
+    // lanes whose slot has no path take pool entries; an empty pool is refilled by the whole wave (stream_pool_kernel)
+    auto take = [&](DualSlot& S) {
+        for (;;) {
+            const uint64_t need = __builtin_amdgcn_ballot_w64(!S.has_path);
+            if (need == 0ull) break;
+            if (pool_count == 0u) {
+                if (exhausted) break;
+                if (cursor >= items_per_batch) {
+                    uint32_t b = 0;
+                    if (lane == 0u) b = atomicAdd(batch_counter, 1u);
+                    b = __builtin_amdgcn_readfirstlane(b);
+                    if (b >= n_batches) { exhausted = true; break; }
+                    const uint32_t tile = b % n_tiles;
+                    ds0 = (b / n_tiles) * batch_spp;
+                    tile_x0 = (tile % tiles_x) * 8u;
+                    tile_row0 = (tile / tiles_x) * 8u;
+                    items_per_batch = 64u * (n_spp - ds0 < batch_spp ? n_spp - ds0 : batch_spp);
+                    cursor = 0;
+                }
+                const uint32_t item = cursor + lane;
+                cursor += 64u;
+                const uint32_t ds = ds0 + (item >> 6);
+                const uint32_t x = tile_x0 + (lane & 7u), row = tile_row0 + (lane >> 3);
+                const bool valid = x < cam.width && row < ra.rows_local;
+                const uint64_t vmask = __builtin_amdgcn_ballot_w64(valid);
+                if (valid) {
+                    const uint32_t y = image_row(ra, row);
+                    Rng rng = rng_seed(ra.seed_key, y * cam.width + x, ra.sample_begin + ds);        // cpu.rs:42-45
+                    const Ray ray = primary_ray(cam, x, y, rng);
+                    const uint32_t e = st_rank(vmask);
+                    pool[0u * 64u + e] = __float_as_uint(ray.o.x); pool[1u * 64u + e] = __float_as_uint(ray.o.y); pool[2u * 64u + e] = __float_as_uint(ray.o.z);
+                    pool[3u * 64u + e] = __float_as_uint(ray.d.x); pool[4u * 64u + e] = __float_as_uint(ray.d.y); pool[5u * 64u + e] = __float_as_uint(ray.d.z);
+                    pool[6u * 64u + e] = rng.s0; pool[7u * 64u + e] = rng.s1;
+                    pool[8u * 64u + e] = ds * (uint32_t)n_pixels + row * cam.width + x;
+                }
+                pool_head = 0u;
+                pool_count = (uint32_t)__builtin_popcountll(vmask);
+                if (pool_count == 0u) continue;
+            }
+            const uint32_t rank = st_rank(need);
+            if (!S.has_path && rank < pool_count) {
+                const uint32_t e = pool_head + rank;
+                S.p.ray.o = v3(__uint_as_float(pool[0u * 64u + e]), __uint_as_float(pool[1u * 64u + e]), __uint_as_float(pool[2u * 64u + e]));
+                S.p.ray.d = v3(__uint_as_float(pool[3u * 64u + e]), __uint_as_float(pool[4u * 64u + e]), __uint_as_float(pool[5u * 64u + e]));
+                S.p.rng.s0 = pool[6u * 64u + e]; S.p.rng.s1 = pool[7u * 64u + e];
+                S.out_idx = pool[8u * 64u + e];
+                S.p.color = v3(0.0f, 0.0f, 0.0f);
+                S.p.atten = v3(1.0f, 1.0f, 1.0f);
+                S.p.remain = ra.max_bounces;
+                S.has_path = true;
+                n_samples++;
+            }
+            const uint32_t wanted = (uint32_t)__builtin_popcountll(need);
+            const uint32_t taken = wanted < pool_count ? wanted : pool_count;
+            pool_head += taken;
+            pool_count -= taken;
+        }
+    };
+    // a finished walk: shade, store the radiance of a finished path; an unfinished one: park it in the slot's leaf stack
+    auto settle = [&](DualSlot& S, Trav& tr, bool done, float2* stk) {
+        if (!S.has_path) return;
+        if (!done) { trav_park(stk, tr); S.walking = true; return; }
+        S.walking = false;
+        if (shade_hit<MODE, false, true>(sc, S.p, tr.prim_best, tr.t_best, background, ctr)) {
+            radiance_store(colors, S.out_idx, S.p.color);
+            S.has_path = false;
+        }
+    };
+
+    TRT_CLK_START(ctr);
+    for (;;) {
+        take(A);
+        take(B);
+        if (__builtin_amdgcn_ballot_w64(A.has_path || B.has_path) == 0ull) break;          // the batches are used up
+        TRT_CLK(ctr, 0);
+        Trav trA = trav_begin(sc, A.p.ray, false), trB = trav_begin(sc, B.p.ray, false);   // a new walk, or the frame of a parked one
+        if (A.has_path) { if (A.walking) trav_unpark(stkA, trA); else n_rays++; }
+        if (B.has_path) { if (B.walking) trav_unpark(stkB, trB); else n_rays++; }
+        const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(A.has_path)) +
+                                 (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(B.has_path));
+        bool doneA = false, doneB = false;
+        walk_compact2<MODE>(sc, nodes16, leaf_list, A.p.ray, trA, A.has_path, B.p.ray, trB, B.has_path, ctr, stkA, stkB, ra.leaf_slots, ra.stragglers,
+                            entered, doneA, doneB);
+        settle(A, trA, doneA, stkA);
+        settle(B, trB, doneB, stkB);
+        TRT_CLK(ctr, 3);
+    }
+    flush_counters<false>(counters, n_samples, n_rays, ctr);
 }
 
 // pixels[idx] += color * (1/spp), samples in order (imager.rs:35,50)
@@ -304,20 +428,19 @@ __global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restric
     V3 acc = v3(0.0f, 0.0f, 0.0f);
     if (accumulate) acc = v3(out[0], out[1], out[2]);
     for (uint32_t s = 0; s < n_spp; s++) {
-        const float* c = colors + 3ull * ((unsigned long long)s * n_pixels + pix);
-        acc = acc + v3(c[0], c[1], c[2]) * inv_spp;
+        const Radiance c = *reinterpret_cast<const Radiance*>(colors + 3ull * ((unsigned long long)s * n_pixels + pix));      // one global_load_dwordx3
+        acc = acc + v3(c.r, c.g, c.b) * inv_spp;
     }
     out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
 }
 
-// Samples per pixel per sample/fold launch pair: as many as keep the radiance buffer within 16 GB (16..256).  Sized for 288 GB of HBM: a
-// launch is a persistent grid that drains a batch queue, and its tail - the last waves finishing their longest paths while the rest of
-// the chip idles - is paid once per launch; the Cornell bench frame went from four 64-spp launches per 256-spp step (4 GB) to one
-// (+1.2 %), random-spheres 1080p from two to one (+2.6 %; profiles/r03_radiance_budget_sweep.txt).  TRT_RADIANCE_GB overrides (1..64).
-uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows) {
+// Samples per pixel per tracing / fold launch pair: as many as keep the radiance buffer within `radiance_gb` GiB (default 16; 16..256 spp).
+// Sized for 288 GB of HBM: a launch is a persistent grid that drains a batch queue, and its tail - the last waves finishing their longest
+// paths while the rest of the chip idles - is paid once per launch; the Cornell bench frame went from four 64-spp launches per 256-spp
+// step (4 GB) to one (+1.2 %), random-spheres 1080p from two to one (+2.6 %; profiles/r03_radiance_budget_sweep.txt).
+uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows, uint32_t radiance_gb) {
     const unsigned long long px = (unsigned long long)width * rows;
-    unsigned long long budget = 16ull << 30;
-    if (const char* e = getenv("TRT_RADIANCE_GB")) { const long g = atol(e); if (g >= 1 && g <= 64) budget = (unsigned long long)g << 30; }
+    const unsigned long long budget = (unsigned long long)(radiance_gb >= 1u && radiance_gb <= 64u ? radiance_gb : 16u) << 30;
     const unsigned long long fit = px ? budget / (px * 12ull) : 256ull;
     uint32_t c = 16;
     while (c < 256u && 2ull * c <= fit) c *= 2u;                                  // power of two in 16..256
@@ -327,9 +450,19 @@ uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows) {
 // Device scratch of one render: [batch counter, 256 bytes] [radiance records: 12 bytes per pixel and sample of a launch].  A render of fewer
 // samples than a full launch holds takes only what it needs.
 constexpr size_t kWorkspaceHeader = 256;
-size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples) {
-    const uint32_t chunk = streamed_chunk_spp(width, rows);
+size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples, uint32_t radiance_gb) {
+    const uint32_t chunk = streamed_chunk_spp(width, rows, radiance_gb);
     return kWorkspaceHeader + (size_t)width * rows * (samples < chunk ? (samples ? samples : 1u) : chunk) * 3 * sizeof(float);
+}
+// ... and the other way round: the samples per pixel a granted workspace holds (at most 256, and few enough for 32-bit record indices).
+// A render that was granted less than it asked for (device memory short: capi.hip halves the request) runs more, shorter launches.
+uint32_t streamed_chunk_that_fits(uint32_t width, uint32_t rows, size_t bytes) {
+    const unsigned long long px = (unsigned long long)width * rows;
+    if (px == 0 || bytes <= kWorkspaceHeader) return 0;
+    unsigned long long c = (bytes - kWorkspaceHeader) / (px * 12ull);
+    if (c > 256ull) c = 256ull;
+    while (c > 1ull && px * c >= (1ull << 32)) c--;
+    return (uint32_t)c;
 }
 
 namespace {
@@ -344,11 +477,15 @@ struct KernelEntry {
     int mode, threads, minw;        // template arguments: scene mode, lanes per workgroup, launch bound (waves per SIMD)
     int walk;                       // WALK_RUNTIME: the kernel picks the walk from its arguments (every knob, counting variants)
     bool pool, stats, lazy;
+    bool dual = false;              // stream_dual_kernel: two paths per lane (MODE_GLOBAL, 16-byte nodes, ray pool)
 };
 #define TRT_POOL(MODE, STATS, MINW, THREADS, WALK, LAZY) \
     KernelEntry{reinterpret_cast<const void*>(&stream_pool_kernel<MODE, STATS, MINW, THREADS, WALK, LAZY>), MODE, THREADS, MINW, WALK, true, STATS, LAZY}
 #define TRT_SAMPLE(MODE, STATS, MINW, THREADS, WALK, LAZY) \
     KernelEntry{reinterpret_cast<const void*>(&stream_sample_kernel<MODE, STATS, MINW, THREADS, WALK, LAZY>), MODE, THREADS, MINW, WALK, false, STATS, LAZY}
+
+#define TRT_DUAL(MINW) \
+    KernelEntry{reinterpret_cast<const void*>(&stream_dual_kernel<MINW, 256>), MODE_GLOBAL, 256, MINW, WALK_COMPACT, true, false, true, true}
 
 // production launches: walk fixed at compile time, lazy colour, no counters
 const KernelEntry kSpecialised[] = {
@@ -359,6 +496,7 @@ const KernelEntry kSpecialised[] = {
     TRT_SAMPLE(MODE_LDS, false, 6, 512, WALK_REGS, true),
     TRT_SAMPLE(MODE_LDS, false, 6, 768, WALK_LDS_STACK, true),
     TRT_POOL(MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true),
+    TRT_DUAL(4), TRT_DUAL(5), TRT_DUAL(6), TRT_DUAL(7), TRT_DUAL(8),
 };
 // every other knob combination and the counting variants: runtime choice of the walk
 const KernelEntry kGeneral[] = {
@@ -378,10 +516,11 @@ const KernelEntry kGeneral[] = {
 };
 #undef TRT_POOL
 #undef TRT_SAMPLE
+#undef TRT_DUAL
 
 const KernelEntry* find_general(int mode, int threads, int minw, bool pool, bool stats) {
     for (const KernelEntry& k : kGeneral)
-        if (k.mode == mode && k.threads == threads && k.minw == minw && k.pool == pool && k.stats == stats) return &k;
+        if (k.mode == mode && k.threads == threads && k.minw == minw && k.pool == pool && k.stats == stats && !k.dual) return &k;
     return nullptr;
 }
 
@@ -391,7 +530,7 @@ const KernelEntry* find_general(int mode, int threads, int minw, bool pool, bool
 // Everything the kernel assumes about its LDS (scene copy | leaf stack: threads x slots x 8 bytes | ray pool: 36 bytes per lane)
 // is decided HERE and nowhere else; trt_streamed_launch_plan exposes the result, and the CPU tests check its invariants for
 // every scene size and every knob (tests/test_host_boundary.py).
-StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra_all, bool stats) {
+StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra_all, const trt_tuning& tn, bool stats) {
     StreamLaunchPlan pl{};
     const size_t scene_bytes = scene_lds_bytes(L);
     const int mode = scene_mode(L);
@@ -403,14 +542,14 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     int threads = 256;
     if (mode == MODE_LDS && L.hot_bytes > 20u * 1024u) {
         threads = (align16(scene_bytes) + 768u * 4u * sizeof(float2)) * 2u <= kLdsPerCu && ra_all.lds_leaf_stack != 0u ? 768 : 512;
-        if (const char* env = getenv("TRT_BIG_THREADS")) { const int t = atoi(env); if (t == 512 || t == 768) threads = t; }
+        if (tn.stream_big_threads == 512u || tn.stream_big_threads == 768u) threads = (int)tn.stream_big_threads;
     }
     // LDS scenes: 6 waves per SIMD.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box
     // step once the compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6,
     // 2.29 at 8)
     int w = mode == MODE_LDS ? 6 : 8;
-    if (const char* env = getenv("TRT_STREAM_MINW")) w = atoi(env);
-    if (w < 5) w = 5;
+    if (tn.stream_waves_per_simd) w = (int)tn.stream_waves_per_simd;
+    if (w < 5 && !(tn.dual_walk != 0u && mode == MODE_GLOBAL && w == 4)) w = 5;      // (4: the two-path kernel only - eight rays per SIMD like 8 x 1)
     if (w > 8) w = 8;
     if (threads == 512 && w > 6) w = 6;
     if (threads == 768) w = 6;
@@ -448,18 +587,31 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack and 256-lane workgroups (LDS scenes at 6
     // waves per SIMD and more, global-memory scenes at 8), and must not cost a resident workgroup either
     const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && w == 8));
-    if (const char* env = getenv("TRT_RAY_POOL")) pool = pool && atoi(env) != 0;
+    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && (w == 8 || tn.dual_walk != 0u)));
+    pool = pool && tn.ray_pool != 0u;
     if (pool) pool = (uint32_t)(kLdsPerCu / (with_stack + pool_bytes)) >= wg_per_cu;
 
     // ---- the kernel instantiation ----
     const int walk = compact ? WALK_COMPACT : (flat && lds_stack) ? WALK_FLAT : lds_stack ? WALK_LDS_STACK : WALK_REGS;
     const bool slots_ok = lds_stack || ra_all.leaf_slots == 0u || ra_all.leaf_slots >= 4u;      // WALK_REGS has 4 register slots
-    const KernelEntry* k = nullptr;
-    if (!stats && slots_ok && L.lazy_color && getenv("TRT_RUNTIME_WALK") == nullptr) {
-        for (const KernelEntry& e : kSpecialised)
-            if (e.mode == mode && e.threads == threads && e.minw == w && e.pool == pool && e.walk == walk) { k = &e; break; }
+    const bool specialise = !stats && slots_ok && L.lazy_color && tn.runtime_walk == 0u;
+    // two paths per lane (stream_dual_kernel): scenes in global memory on 16-byte nodes with the ray pool; two leaf stacks per lane, as deep
+    // as fit beside the pool (2..4 slots: a parked walk needs two)
+    bool dual = tn.dual_walk != 0u && specialise && compact && pool && threads == 256;
+    if (dual) {
+        uint32_t ds = ra_all.leaf_slots == 0u ? 4u : (ra_all.leaf_slots < 2u ? 2u : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots));
+        while (ds > 2u && (align16(scene_bytes) + 2u * (size_t)threads * ds * sizeof(float2) + pool_bytes) * wg_per_cu > kLdsPerCu) ds--;
+        if ((align16(scene_bytes) + 2u * (size_t)threads * ds * sizeof(float2) + pool_bytes) * wg_per_cu > kLdsPerCu) dual = false;
+        else slots = ds;
     }
+    const size_t stack_total = dual ? 2u * (size_t)threads * slots * sizeof(float2) : stack_bytes;
+    const KernelEntry* k = nullptr;
+    if (specialise) {
+        for (const KernelEntry& e : kSpecialised)
+            if (e.mode == mode && e.threads == threads && e.minw == w && e.pool == pool && e.walk == walk && e.dual == dual) { k = &e; break; }
+    }
+    if (!k) dual = false;
+    if (!dual && w < 5) { w = 5; wg_per_cu = (uint32_t)(w * 4 * 64 / threads); }             // four waves per SIMD exist for the two-path kernel only
     pl.specialised = k != nullptr;
     if (!k) {
         // the general instantiations exist for fewer (waves, pool) combinations than the knobs can ask for: take the nearest one
@@ -483,29 +635,32 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
         pool = kpool;
         if (kw >= 5 && kw < w) { w = kw; wg_per_cu = (uint32_t)(w * 4 * 64 / threads); }
     }
-    const size_t lds_bytes = lds_stack ? with_stack + (pool ? pool_bytes : 0u) : scene_bytes;
+    const size_t lds_bytes = lds_stack ? align16(scene_bytes) + (dual ? stack_total : stack_bytes) + (pool ? pool_bytes : 0u) : scene_bytes;
     if (lds_bytes) { const uint32_t by_lds = (uint32_t)(kLdsPerCu / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
     pl.mode = mode; pl.threads = threads; pl.waves_per_simd = w; pl.wg_per_cu = wg_per_cu; pl.slots = slots;
-    pl.lds_stack = lds_stack; pl.flat = flat && lds_stack; pl.compact = compact; pl.pool = pool; pl.walk = walk;
+    pl.lds_stack = lds_stack; pl.flat = flat && lds_stack; pl.compact = compact; pl.pool = pool; pl.walk = walk; pl.dual = dual;
     pl.lds_bytes = lds_bytes; pl.scene_lds_bytes = scene_bytes;
     pl.kernel = k ? k->fn : nullptr;
     pl.kernel_minw = k ? k->minw : 0; pl.kernel_threads = k ? k->threads : 0; pl.kernel_walk = k ? k->walk : 0; pl.kernel_pool = k ? k->pool : false;
     pl.kernel_stats = k ? k->stats : false;
-    pl.kernel_name = pool ? "trt::stream_pool_kernel" : "trt::stream_sample_kernel";
+    pl.kernel_name = dual ? "trt::stream_dual_kernel" : pool ? "trt::stream_pool_kernel" : "trt::stream_sample_kernel";
     return pl;
 }
 
 // Name of the kernel that dominates a streamed render of this scene (for profiles and bench.py's roofline line).
-const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra) { return streamed_launch_plan(L, ra, false).kernel_name; }
+const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra, const trt_tuning& tn) { return streamed_launch_plan(L, ra, tn, false).kernel_name; }
 
-hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra_all, void* workspace, float* d_accum,
-                           unsigned long long* d_counters, bool stats, hipStream_t stream) {
+hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra_all, const trt_tuning& tn, void* workspace, size_t workspace_bytes,
+                           float* d_accum, unsigned long long* d_counters, bool stats, hipStream_t stream) {
     if (ra_all.rows_local == 0 || cam.width == 0) return hipSuccess;
     const unsigned long long n_pixels = (unsigned long long)ra_all.rows_local * cam.width;
     uint32_t* batch_counter = static_cast<uint32_t*>(workspace);                                     // layout: streamed_workspace_bytes
     float* colors = reinterpret_cast<float*>(static_cast<char*>(workspace) + kWorkspaceHeader);
     const uint32_t samples_all = ra_all.sample_end - ra_all.sample_begin;
-    const uint32_t chunk_full = streamed_chunk_spp(cam.width, ra_all.rows_local);
+    uint32_t chunk_full = streamed_chunk_spp(cam.width, ra_all.rows_local, tn.radiance_gb);
+    const uint32_t granted = streamed_chunk_that_fits(cam.width, ra_all.rows_local, workspace_bytes);      // the scratch in hand decides, not the wish
+    if (granted == 0u) return hipErrorInvalidValue;
+    if (chunk_full > granted) chunk_full = granted;
     const uint32_t chunk = samples_all < chunk_full ? (samples_all ? samples_all : 1u) : chunk_full;
     uint32_t tiles_x = (cam.width + 7u) / 8u;
     const uint32_t tiles_y = (ra_all.rows_local + 7u) / 8u;
@@ -514,12 +669,12 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const StreamLaunchPlan pl = streamed_launch_plan(sc.L, ra_all, stats);
+    const StreamLaunchPlan pl = streamed_launch_plan(sc.L, ra_all, tn, stats);
     if (pl.kernel == nullptr) return hipErrorInvalidDeviceFunction;               // no instantiation for this plan: a bug, never a fallback
     // the kernel's assumptions about its dynamic LDS, checked where the launch is made (scene copy | leaf stack | ray pool)
     {
         size_t need = pl.scene_lds_bytes;
-        if (pl.lds_stack) need = align16(need) + (size_t)pl.threads * pl.slots * sizeof(float2) + (pl.pool ? (size_t)pl.threads * kPoolDwords * sizeof(uint32_t) : 0u);
+        if (pl.lds_stack) need = align16(need) + (pl.dual ? 2u : 1u) * (size_t)pl.threads * pl.slots * sizeof(float2) + (pl.pool ? (size_t)pl.threads * kPoolDwords * sizeof(uint32_t) : 0u);
         if (need != pl.lds_bytes || pl.lds_bytes > kLdsPerCu || pl.kernel_threads != pl.threads || (pl.pool && !pl.lds_stack) ||
             (pl.flat && pl.slots < 2u) || (pl.kernel_pool != pl.pool)) return hipErrorInvalidConfiguration;
     }
@@ -540,14 +695,12 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         ra.lds_leaf_stack = pl.lds_stack ? 1u : 0u;
         if (pl.lds_stack) ra.leaf_slots = pl.slots;
         if (walk_of_plan == WALK_LDS_STACK) {                                   // the LDS tree walk's own straggler threshold
-            ra.stragglers = kLdsStragglers;
-            if (const char* env = getenv("TRT_LDS_STRAGGLERS")) ra.stragglers = (uint32_t)atoi(env);
+            ra.stragglers = tn.lds_stragglers;
         }
         if (!pl.lds_stack || pl.slots < 2u) ra.stragglers = 0u;                 // a parked walk occupies two slots of the lane's LDS leaf stack (rt_path.h trav_park)
         ra.sample_begin = s0;
         ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;
-        uint32_t batch_spp = kBatchSpp;
-        if (const char* env = getenv("TRT_STREAM_BATCH_SPP")) batch_spp = (uint32_t)atoi(env) ? (uint32_t)atoi(env) : kBatchSpp;
+        uint32_t batch_spp = tn.stream_batch_spp ? tn.stream_batch_spp : kBatchSpp;
         uint32_t n_batches = n_tiles * ((ra.sample_end - ra.sample_begin + batch_spp - 1u) / batch_spp);
         uint32_t grid_x = resident;
         const uint32_t max_useful = (n_batches + waves_per_wg - 1u) / waves_per_wg;   // one batch per wave at least

@@ -277,8 +277,8 @@ size_t wavefront_workspace_bytes(uint32_t width, uint32_t rows) {
     return tiles * kWfSlots * (4 * sizeof(float4) + sizeof(uint2));
 }
 
-hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, void* workspace, float* d_accum,
-                            unsigned long long* d_counters, bool stats, uint32_t serve_min, hipStream_t stream) {
+hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra, const trt_tuning& tn, void* workspace, float* d_accum,
+                            unsigned long long* d_counters, bool stats, hipStream_t stream) {
     const uint32_t tiles_x = (cam.width + kWfTileW - 1) / kWfTileW, tiles_y = (ra.rows_local + kWfTileH - 1) / kWfTileH;
     if (tiles_x == 0 || tiles_y == 0) return hipSuccess;
     const size_t n_slots = (size_t)tiles_x * tiles_y * kWfSlots;
@@ -291,7 +291,7 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
     st.rng = reinterpret_cast<uint2*>(st.s3 + n_slots);
     const size_t lds_bytes = scene_lds_bytes(sc.L) + sizeof(WfLds);
     const dim3 grid(tiles_x * tiles_y), block(kWfThreads);
-    if (serve_min == 0) serve_min = 12;        // flat optimum 8..24 on the 100 k-sphere scene
+    const uint32_t serve_min = tn.wf_serve_min ? tn.wf_serve_min : 12u;        // flat optimum 8..24 on the 100 k-sphere scene
     auto go = [&](auto kernel) -> hipError_t {
         if (lds_bytes > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -308,7 +308,7 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
         case MODE_HYBRID: return stats ? go(wavefront_kernel<MODE_HYBRID, true>) : go(wavefront_kernel<MODE_HYBRID, false>);
         default: {
             int w = 6;                              // 80 VGPRs, 12 B of scratch: +2 % over the 87-VGPR / 5-wave allocation; 7, 8: slower
-            if (const char* e = getenv("TRT_WF_MINW")) w = atoi(e);
+            if (tn.wf_waves_per_simd) w = (int)tn.wf_waves_per_simd;
             if (w >= 8) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 8>) : go(wavefront_kernel<MODE_GLOBAL, false, 8>);
             if (w == 7) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 7>) : go(wavefront_kernel<MODE_GLOBAL, false, 7>);
             if (w == 6) return stats ? go(wavefront_kernel<MODE_GLOBAL, true, 6>) : go(wavefront_kernel<MODE_GLOBAL, false, 6>);
