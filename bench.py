@@ -108,7 +108,8 @@ def usable_cores():
 def cpu_baseline(trt, desc, depth, budget_s):
     """The CPU oracle (a port of the reference's CPU path) on a bounded sample of the same workload: whole-image passes of 1 spp
     until the budget is spent - about two thirds of it on all host cores (the headline CPU figure), the rest on ONE thread
-    (the reference's configs[0] is a single-thread run)."""
+    (the reference's configs[0] is a single-thread run).  Returns (block, frame, spp, rays): the all-core leg's
+    frame holds samples [0, spp) of the 4096-spp frame - main() renders the same samples on the GPU and compares (`parity`)."""
     from oracle import orc
     import numpy as np
     cores = usable_cores()
@@ -127,17 +128,107 @@ def cpu_baseline(trt, desc, depth, budget_s):
             spp_done += 1
             dt = time.perf_counter() - t0
             if dt >= seconds or spp_done >= 64:
-                return rays, spp_done, dt
+                return rays, spp_done, dt, acc
 
-    rays, spp_done, dt = run(cores, budget_s * 2.0 / 3.0)
+    rays, spp_done, dt, frame = run(cores, budget_s * 2.0 / 3.0)
     out = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
            "sample": f"{spp_done} spp of the {cam.width}x{cam.height} depth-{depth} frame ({rays} rays, {dt:.1f} s)"}
     # one thread: a 1-spp pass over the top rows of the frame, sized from the all-core rate to fit the rest of the budget
     per_thread = rays / dt / max(cores, 1)
     rows = int(min(cam.height, max(16, (budget_s / 3.0) * per_thread / max(rays / spp_done / cam.height, 1.0))))
-    r1, s1, d1 = run(1, budget_s / 3.0, row_end=rows)
+    r1, s1, d1, _ = run(1, budget_s / 3.0, row_end=rows)
     out["single_thread"] = {"value": r1 / d1 / 1e6, "unit": "Mray/s", "cores": 1,
                             "sample": f"{s1} spp of the top {rows} rows ({r1} rays, {d1:.1f} s)"}
+    return out, frame, spp_done, rays
+
+
+def valu_roofline(key, avg_ms, rays_per_launch, warnings, single_gpu=True):
+    """The VALU lane-slot block of one kernel from its stored PMC profile (per-ray instruction counts) and its launch time measured live."""
+    prof, stale = pmc_profile(key)
+    out = {"frac": None, "achieved": None, "pmc_key": key, "pmc_stale": stale}
+    if prof is not None and not stale and avg_ms and rays_per_launch > 0:
+        prof_rays = prof.get("rays_per_launch")
+        if not prof_rays:
+            if single_gpu:
+                prof_rays = rays_per_launch              # entries older than the field: same workload, same rays
+            else:
+                warnings.append("PMC entry has no rays_per_launch: cannot scale it to this rank's share")
+        if prof_rays:
+            scale = rays_per_launch / prof_rays
+            insts = prof["SQ_INSTS_VALU"] * scale
+            lanes = prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_INSTS_VALU"] if prof.get("SQ_THREAD_CYCLES_VALU") else None   # active lanes per VALU instruction
+            hbm = prof["hbm_bytes_per_launch"] * scale
+            issue_rate = insts / (avg_ms * 1e-3) / 1e9                                    # G wave-instructions / s
+            issue_frac = issue_rate / VALU_PEAK_GINST
+            out.update({
+                "issue_frac": round(issue_frac, 4), "issue_achieved_Ginst_s": round(issue_rate, 1), "issue_peak_Ginst_s": round(VALU_PEAK_GINST, 1),
+                "valu_wave_insts_per_launch": int(insts), "valu_wave_insts_per_ray": round(prof["SQ_INSTS_VALU"] / prof_rays, 2) if prof_rays else None,
+                "cycles_per_valu_inst_per_simd": round(avg_ms * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
+                "peak_cycles_per_valu_inst_per_simd": 2.0, "mean_active_lanes": round(lanes, 1) if lanes else None,
+                "salu_insts_per_launch": int(prof.get("SQ_INSTS_SALU", 0) * scale), "traffic": int(hbm),
+                "hbm_physical_GBps": round(hbm / (avg_ms * 1e-3) / 1e9, 1), "hbm_physical_frac": round(hbm / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "pmc_source": prof.get("source")})
+            if lanes:
+                out["achieved"] = round(issue_rate * lanes / 1e3, 2)
+                out["frac"] = round(issue_frac * lanes / 64.0, 4)
+                out["lane_slot_frac"] = out["frac"]
+            if issue_frac > 1.0 or out["hbm_physical_frac"] > 1.0:
+                warnings.append(f"{key}: a fraction above 1: the stored PMC profile does not describe this run (other box clock, other build?)")
+    elif prof is None:
+        warnings.append(f"no PMC profile for {key} under profiles/pmc_kernels.json: frac is null")
+    elif stale:
+        warnings.append(f"the PMC profile of {key} was taken from other kernel sources (pmc_stale): frac is null until tools/pmc_bench.sh is re-run")
+    return out
+
+
+OTHER_SCENES = (   # BASELINE configs[2] and configs[4] at their own sizes: short untimed-by-the-driver runs reported beside the headline
+    ("random_spheres", 1920, 1080, 256, 3, 1),
+    ("sphere_grid", 3840, 2160, 16, 2, 1),
+)
+
+
+def short_run(trt, torch, dev, scene_name, W, H, S, steps, warmup, depth, backend_name, backend):
+    """A few steps of another BASELINE scene at its own size on this GPU, after the timed region of the headline workload: value,
+    ms per step, the dominant kernel's launch time (HIP events on its launch stream) and its lane-slot fraction."""
+    desc = {"random_spheres": trt.scenes.random_spheres, "sphere_grid": lambda w, h: trt.scenes.sphere_grid(100000, w, h)}[scene_name](W, H)
+    world, cam = trt.world_from_description(desc)
+    scene = world.get_bvh()
+    renderer = trt.Renderer(FRAME_SPP, 1, depth, False, desc["background"], seed=1, backend=backend)
+    acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    ctr = torch.zeros(16, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        s0, s1, accumulate = step_range(i, S)
+        renderer.render_device(cam, scene, acc.data_ptr(), stream.cuda_stream, ctr.data_ptr(), sample_begin=s0, sample_end=s1, accumulate=accumulate)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    ctr.zero_()
+    torch.cuda.synchronize()
+    trt._lib.check(trt.lib.trt_kernel_timing_begin())
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(warmup + k)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_n = C.c_double(0.0), C.c_uint32(0)
+    trt._lib.check(trt.lib.trt_kernel_timing_end(C.byref(k_ms), C.byref(k_n)))
+    rays, samples = int(ctr[1].item()), int(ctr[0].item())
+    n_launch = int(k_n.value)
+    avg_ms = k_ms.value / n_launch if n_launch else None
+    warnings = []
+    key = f"{scene_name}_{W}x{H}_d{depth}_spp{S}_{backend_name}"
+    rf = valu_roofline(key, avg_ms, rays / n_launch if n_launch else 0.0, warnings)
+    kernel = trt.lib.trt_dominant_kernel(scene._h, C.byref(cam.pod), C.byref(renderer.params())).decode()
+    out = {"workload": f"{scene_name} {W}x{H}, depth {depth}, {S} spp per step (of 4096), {backend_name}, seed 1", "value": round(rays / elapsed / 1e6, 2),
+           "unit": "Mray/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "rays": rays, "samples": samples,
+           "roofline": {"kernel": kernel, "avg_launch_ms": round(avg_ms, 4) if avg_ms else None, "launches_timed": n_launch,
+                        "frac": rf["frac"], "issue_frac": rf.get("issue_frac"), "mean_active_lanes": rf.get("mean_active_lanes"),
+                        "cycles_per_valu_inst_per_simd": rf.get("cycles_per_valu_inst_per_simd"), "traffic": rf.get("traffic"),
+                        "pmc_key": key, "pmc_stale": rf["pmc_stale"], "warnings": warnings}}
+    del acc, scene, world
     return out
 
 
@@ -153,8 +244,10 @@ def main():
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--depth", type=int, default=50)
     ap.add_argument("--scene", default="cornell", choices=["cornell", "random_spheres", "sphere_grid"])
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="budget of the cpu_baseline leg; 0 = measurement only: no CPU leg, no parity block, no other scenes (what the tools/ scripts use)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the untimed counter pass")
+    ap.add_argument("--no-other-scenes", action="store_true", help="skip the short runs of the other two BASELINE scenes after the timed region")
     args = ap.parse_args()
 
     import torch
@@ -286,46 +379,13 @@ def main():
     my_rays = int(ctr[1].item())
     rays_per_launch = my_rays / n_launch if n_launch else 0.0
     key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}"
-    prof, stale = pmc_profile(key)
     roofline = {"bound": "valu", "kernel": kernel_name, "achieved": None, "peak": round(VALU_PEAK_GINST * 64.0 / 1e3, 2),
                 "unit": "T f32 lane-instructions/s (VALU wave-instructions x active lanes)", "frac": None, "traffic": None,
                 "frac_is": "lane-slot fraction: VALU lane-instructions per second / (1024 SIMDs x 2.4 GHz / 2 cycles x 64 lanes); "
                            "instruction counts per ray from a stored PMC profile of the same kernel sources, launch time measured live",
                 "avg_launch_ms": round(avg_ms, 4) if avg_ms else None, "launches_per_step": launches_per_step, "launches_timed": n_launch,
-                "rays_per_launch": int(rays_per_launch), "step_ms_by_events": round(sum(launch_ms) / len(launch_ms), 4),
-                "pmc_key": key, "pmc_stale": stale, "rank": rank}
-    if prof is not None and not stale and avg_ms and rays_per_launch > 0:
-        prof_rays = prof.get("rays_per_launch")
-        if not prof_rays:
-            if world_size == 1:
-                prof_rays = rays_per_launch              # entries older than the field: same workload, same rays
-            else:
-                warnings.append("PMC entry has no rays_per_launch: cannot scale it to this rank's share")
-        if prof_rays:
-            scale = rays_per_launch / prof_rays
-            insts = prof["SQ_INSTS_VALU"] * scale
-            lanes = prof["SQ_THREAD_CYCLES_VALU"] / prof["SQ_INSTS_VALU"] if prof.get("SQ_THREAD_CYCLES_VALU") else None   # active lanes per VALU instruction
-            hbm = prof["hbm_bytes_per_launch"] * scale
-            issue_rate = insts / (avg_ms * 1e-3) / 1e9                                    # G wave-instructions / s
-            issue_frac = issue_rate / VALU_PEAK_GINST
-            roofline.update({
-                "issue_frac": round(issue_frac, 4), "issue_achieved_Ginst_s": round(issue_rate, 1), "issue_peak_Ginst_s": round(VALU_PEAK_GINST, 1),
-                "valu_wave_insts_per_launch": int(insts), "valu_wave_insts_per_ray": round(prof["SQ_INSTS_VALU"] / prof_rays, 2) if prof_rays else None,
-                "cycles_per_valu_inst_per_simd": round(avg_ms * 1e-3 * CLOCK_GHZ * 1e9 * N_SIMD / insts, 3),
-                "peak_cycles_per_valu_inst_per_simd": 2.0, "mean_active_lanes": round(lanes, 1) if lanes else None,
-                "salu_insts_per_launch": int(prof.get("SQ_INSTS_SALU", 0) * scale), "traffic": int(hbm),
-                "hbm_physical_GBps": round(hbm / (avg_ms * 1e-3) / 1e9, 1), "hbm_physical_frac": round(hbm / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "pmc_source": prof.get("source")})
-            if lanes:
-                roofline["achieved"] = round(issue_rate * lanes / 1e3, 2)
-                roofline["frac"] = round(issue_frac * lanes / 64.0, 4)
-                roofline["lane_slot_frac"] = roofline["frac"]
-            if issue_frac > 1.0 or roofline["hbm_physical_frac"] > 1.0:
-                warnings.append("a fraction above 1: the stored PMC profile does not describe this run (other box clock, other build?)")
-    elif prof is None:
-        warnings.append("no PMC profile for this workload under profiles/pmc_kernels.json: frac is null")
-    elif stale:
-        warnings.append("the PMC profile was taken from other kernel sources (pmc_stale): frac is null until tools/pmc_bench.sh is re-run")
+                "rays_per_launch": int(rays_per_launch), "step_ms_by_events": round(sum(launch_ms) / len(launch_ms), 4), "rank": rank}
+    roofline.update(valu_roofline(key, avg_ms, rays_per_launch, warnings, single_gpu=world_size == 1))
     if not args.no_roofline_pass and rows_local > 0:
         # untimed: the same K launches with the counting kernel variant -> exact algorithmic bytes of those launches
         sctr = torch.zeros(16, dtype=torch.int64, device=dev)
@@ -362,9 +422,37 @@ def main():
         per_rank = [{"rank": r, "avg_launch_ms": round(float(t[0]), 4), "launches": int(t[1]), "rays": int(t[2]), "image_rows": int(t[3]),
                      "frac": round(float(t[4]), 4) if float(t[4]) > 0 else None} for r, t in enumerate(table)]
 
-    cpu = None
+    # ---- outside the timed region, rank 0 at N = 1 only: the CPU oracle on this box's host cores, a pixel-for-pixel parity check of the
+    # GPU path against the frame that leg renders, and short runs of the other two BASELINE scenes.  None of it can end the run.
+    cpu = parity = None
+    other = []
     if rank == 0 and world_size == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(trt, desc, args.depth, args.cpu_seconds)
+        cpu, cpu_frame, cpu_spp, cpu_rays = cpu_baseline(trt, desc, args.depth, args.cpu_seconds)
+        try:
+            import numpy as np
+            pctr = torch.zeros(16, dtype=torch.int64, device=dev)
+            pacc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+            renderer.render_device(cam, scene, pacc.data_ptr(), stream.cuda_stream, pctr.data_ptr(), sample_begin=0, sample_end=cpu_spp, accumulate=0)
+            torch.cuda.synchronize()
+            gpu_frame = pacc.cpu().numpy()
+            same = bool(np.array_equal(gpu_frame.view(np.uint32), np.ascontiguousarray(cpu_frame, np.float32).view(np.uint32)))
+            with np.errstate(invalid="ignore"):
+                delta = float(np.nanmax(np.abs(gpu_frame - cpu_frame)))
+            parity = {"against": "the oracle frame of the cpu_baseline leg (oracle/rt_oracle.c, the CPU restatement of cpu.rs:39-65 / imager.rs:50)",
+                      "workload": f"{args.scene} {W}x{H}, depth {args.depth}, samples [0, {cpu_spp}) of 4096, seed 1, whole frame",
+                      "spp": cpu_spp, "pixels": W * H, "bit_identical": same, "max_abs_delta": delta, "tolerance": 1e-3,
+                      "rays_gpu": int(pctr[1].item()), "rays_oracle": int(cpu_rays), "ray_counts_equal": int(pctr[1].item()) == int(cpu_rays)}
+            del pacc, gpu_frame
+        except Exception as e:                                   # noqa: BLE001 - the bench line must still be printed
+            parity = {"error": repr(e)}
+    if rank == 0 and world_size == 1 and args.cpu_seconds > 0 and not args.no_other_scenes:
+        for name, ow, oh, ospp, osteps, owarm in OTHER_SCENES:
+            if name == args.scene and (ow, oh) == (W, H):
+                continue
+            try:
+                other.append(short_run(trt, torch, dev, name, ow, oh, ospp, osteps, owarm, args.depth, args.backend, backend))
+            except Exception as e:                               # noqa: BLE001
+                other.append({"workload": name, "error": repr(e)})
 
     if rank == 0:
         if frame is not None:
@@ -379,7 +467,7 @@ def main():
                        "rays": total_rays, "samples": total_samples, "image_rows_per_gpu": rows_local,
                        "parallelism": (f"image bands x{world_size}" + (" (REHEARSAL: all ranks on cuda:0, gloo)" if rehearsal else ""))
                                       if world_size > 1 else "single GPU"},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_scenes": other,
         }
         if per_rank is not None:
             out["roofline_per_rank"] = per_rank

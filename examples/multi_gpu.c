@@ -4,7 +4,13 @@
  * allocation of the destination frame and the copy back.
  *
  *   hipcc -x c -std=c11 -I include examples/multi_gpu.c -L tiny-raytracer_amd -ltinyrt -Wl,-rpath,$PWD/tiny-raytracer_amd -o multi_gpu
- *   ./multi_gpu [width height spp]
+ *   ./multi_gpu [--verify-each-device] [width height spp]
+ *
+ * --verify-each-device: before anything is gathered, the whole frame is rendered on EVERY visible ordinal by itself and compared with
+ * device 0's - scene replication (the blob uploaded per device), the per-device contexts and every device's kernels are validated one
+ * by one, so that on a new multi-GPU box a wrong frame is pinned to a device before the gather (peer access, strided device-to-device
+ * copies) comes into play.  The report also says how the gather went (trt_stats.gather_per_band: shards that fell back to band-by-band
+ * copies).
  *
  * On a one-GPU box it renders with shards {0, 0} (two shards sharing the device), which exercises the same band layout; the
  * peer path (hipDeviceEnablePeerAccess + device-to-device gather between two ordinals) needs a box with at least two GPUs. */
@@ -25,6 +31,8 @@ static int quad(trt_world *w, float cx, float cy, float cz, float ux, float uy, 
 }
 
 int main(int argc, char **argv) {
+    int verify_each = 0;
+    if (argc > 1 && strcmp(argv[1], "--verify-each-device") == 0) { verify_each = 1; argc--; argv++; }
     const uint32_t W = argc > 2 ? (uint32_t)atoi(argv[1]) : 512, H = argc > 2 ? (uint32_t)atoi(argv[2]) : 500;   /* 500: ragged last band */
     const uint32_t spp = argc > 3 ? (uint32_t)atoi(argv[3]) : 16;
     int ndev = trt_device_count();
@@ -59,6 +67,19 @@ int main(int argc, char **argv) {
     trt_stats st1, stn;
     OK(trt_set_device(0));
     OK(trt_render(scene, &cam, &p, one, &st1));                                  /* device 0 alone */
+    if (verify_each) {                                                          /* ... and every other device alone, before any gather */
+        int bad = 0;
+        for (int d = 0; d < ndev; d++) {
+            trt_stats sd;
+            OK(trt_set_device(d));
+            OK(trt_render(scene, &cam, &p, all, &sd));
+            const int ok = memcmp(one, all, n * sizeof(float)) == 0 && sd.rays == st1.rays;
+            printf("device %d alone: %.1f ms, %llu rays, frame %s\n", d, sd.kernel_ms, (unsigned long long)sd.rays, ok ? "identical to device 0's" : "DIFFERS");
+            bad += !ok;
+        }
+        OK(trt_set_device(0));
+        if (bad) { fprintf(stderr, "%d device(s) render another frame than device 0: not gathering\n", bad); return 1; }
+    }
 
     int devices[64];
     uint32_t shards = ndev > 1 ? (uint32_t)ndev : 2u;
@@ -74,8 +95,10 @@ int main(int argc, char **argv) {
     HIP(hipFree(d_frame));
 
     int same = memcmp(one, all, n * sizeof(float)) == 0 && st1.rays == stn.rays;
-    printf("%u x %u, %u spp: %d device(s) visible, %u shards, %.1f ms on the slowest shard (one device: %.1f ms), %llu rays, frames %s\n", W, H, spp,
-           ndev, shards, stn.kernel_ms, st1.kernel_ms, (unsigned long long)stn.rays, same ? "IDENTICAL" : "DIFFER");
+    printf("%u x %u, %u spp: %d device(s) visible, %u shards, %.1f ms on the slowest shard (one device: %.1f ms), %llu rays, gather: %s, frames %s\n", W, H, spp,
+           ndev, shards, stn.kernel_ms, st1.kernel_ms, (unsigned long long)stn.rays,
+           stn.gather_per_band ? "band by band on some shards (no peer access, or the strided peer copy was refused)" : "one strided 2-D copy per shard",
+           same ? "IDENTICAL" : "DIFFER");
     OK(trt_scene_trim(scene));
     trt_scene_destroy(scene);
     free(one); free(all);

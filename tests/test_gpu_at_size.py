@@ -1,5 +1,5 @@
-"""BASELINE configs[1] and configs[2] at FULL size on the DEFAULT backend: Cornell 800x800 and the random-spheres
-scene at 1920x1080, depth 50, through the streamed backend's production plans (lock-step leaf list + ray pool; 768-lane
+"""BASELINE configs[1], configs[2] and configs[3] at FULL image size on the DEFAULT backend: Cornell 800x800 and
+2048x2048 and the random-spheres scene at 1920x1080, depth 50, through the streamed backend's production plans (lock-step leaf list + ray pool; 768-lane
 workgroups with the LDS leaf stack) - the shapes `bench.py --scene ...` measures.  In the form of tests/test_gpu_cfg5.py:
 
  * oracle parity, bit for bit, on the whole frame at a few spp (the oracle needs a second or two) and on 16-row bands rendered
@@ -17,6 +17,8 @@ DEPTH = 50
 CASES = {
     "cfg2_cornell_800": dict(scene="cornell", w=800, h=800, plan=dict(walk=2, threads_per_workgroup=256, ray_pool=1, specialised=1)),
     "cfg3_random_spheres_1080p": dict(scene="random_spheres", w=1920, h=1080, plan=dict(walk=1, threads_per_workgroup=768, ray_pool=0, specialised=1)),
+    # BASELINE configs[3] at its own image size (round 4): the frame bench.py times, against the oracle pixel for pixel
+    "cfg4_cornell_2048": dict(scene="cornell", w=2048, h=2048, plan=dict(walk=2, threads_per_workgroup=256, ray_pool=1, specialised=1)),
 }
 
 
@@ -130,3 +132,43 @@ def test_at_size_schedules_agree(trt, case):
             continue
         assert rays == ref_rays, (case, env)
         assert torch.equal(acc.view(torch.int32), ref.view(torch.int32)), (case, env)
+
+
+FULL_SPP = {
+    # BASELINE configs[2] and configs[4] at their FULL sample counts, once each: (scene, W, H, spp, split) - `split` lies inside
+    # the first launch's sample range, so the two progressive passes cut the frame's launches (512 spp = 2 x 256 at 1080p, 256 spp = 2 x 128
+    # at 2160p: streamed.hip streamed_chunk_spp) at other places than the one-pass render does
+    "cfg3_random_spheres_1080p_512spp": (lambda trt: trt.scenes.random_spheres(1920, 1080), 512, 300),
+    "cfg5_sphere_grid100k_2160p_256spp": (lambda trt: trt.scenes.sphere_grid(100000, 3840, 2160), 256, 100),
+}
+
+
+@pytest.mark.parametrize("case", sorted(FULL_SPP))
+def test_full_sample_count_streamed_equals_megakernel_and_progressive(trt, case):
+    """The whole config, every sample: the default (streamed) backend's chunked launches against the megakernel - one lane per pixel walking
+    its samples in order, no radiance buffer, no fold pass - bit for bit with equal ray counts, and two progressive passes that straddle
+    the launch boundary against the one-pass render."""
+    import torch
+    dev = torch.device("cuda:0")
+    mk, spp, split = FULL_SPP[case]
+    desc = mk(trt)
+    pw, pcam = trt.world_from_description(desc)
+    W, H = pcam.get_image_size()
+    stream = torch.cuda.current_stream()
+    chunk = trt.lib.trt_streamed_chunk_spp(W, H)
+    assert chunk < spp and split % chunk != 0, "the case no longer crosses a launch boundary"
+    frames, rays = {}, {}
+    for name, backend, passes in (("streamed", trt.BACKEND_STREAMED, [(0, spp)]), ("streamed, two passes", trt.BACKEND_STREAMED, [(0, split), (split, spp)]),
+                                  ("megakernel", trt.BACKEND_MEGAKERNEL, [(0, spp)])):
+        r = trt.Renderer(spp, 1, DEPTH, False, desc["background"], seed=1, backend=backend)
+        acc = torch.zeros((H, W, 3), device=dev)
+        ctr = torch.zeros(16, dtype=torch.int64, device=dev)
+        for k, (s0, s1) in enumerate(passes):
+            r.render_device(pcam, pw.get_bvh(), acc.data_ptr(), stream.cuda_stream, ctr.data_ptr(), sample_begin=s0, sample_end=s1, accumulate=int(k > 0))
+        torch.cuda.synchronize()
+        frames[name], rays[name] = acc, int(ctr[1].item())
+        assert int(ctr[0].item()) == W * H * spp, name
+    assert rays["streamed"] == rays["megakernel"] == rays["streamed, two passes"] and rays["streamed"] > W * H * spp
+    for name in ("streamed, two passes", "megakernel"):
+        assert torch.equal(frames[name].view(torch.int32), frames["streamed"].view(torch.int32)), (case, name)
+    assert torch.isfinite(frames["streamed"]).all() and float(frames["streamed"].mean()) > 0.01

@@ -206,6 +206,10 @@ def test_multi_gpu_c_example_renders_identical_frames(tmp_path):
     exe = _build_multi_gpu_example(tmp_path)
     r = subprocess.run([exe, "512", "500", "16"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "IDENTICAL" in r.stdout, r.stdout + r.stderr
+    # the mode a new multi-GPU box is brought up with: every visible ordinal renders the whole frame alone before anything is gathered
+    r = subprocess.run([exe, "--verify-each-device", "320", "200", "8"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "device 0 alone" in r.stdout and "DIFFERS" not in r.stdout and "IDENTICAL" in r.stdout, r.stdout + r.stderr
+    assert "one strided 2-D copy per shard" in r.stdout                   # host or same-device gather: never band by band
 
 
 

@@ -10,8 +10,8 @@
 //    ~3.6 k rays: small against a wave's share even of one GPU's eighth of a frame) from a global counter, one
 //    returning atomic per batch (<10 per us, the counter word saturates near 88); inside a wave every lane takes the next item of
 //    the batch whenever its path ends (ballot + mbcnt ranks on a wave-uniform cursor, no atomics), so no lane waits
-//    for a neighbour's longer chain or a more expensive pixel.  The finished sample's radiance (12 B) goes to an HBM
-//    buffer laid out [sample][pixel].
+//    for a neighbour's longer chain or a more expensive pixel.  The finished sample's radiance (12 B, one store) goes to an HBM
+//    buffer laid out [tile][sample][lane of the tile] (stream_fold_kernel).
 //  * FOLD kernel: one lane per pixel adds that pixel's radiances in sample order,
 //    `pixels[idx] += color * (1/spp)` (imager.rs:50): the same sequence of f32 additions as the reference, so the
 //    frame is bit-identical to the megakernel's and the oracle's whatever lane computed which sample.
@@ -44,20 +44,19 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     const uint32_t lane = threadIdx.x & 63u;
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
     const uint32_t n_spp = ra.sample_end - ra.sample_begin;
-    const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
     // postponed-leaf stack (rt_path.h walk_fast_lds): behind the scene copy, leaf_slots x 64 x 8 bytes per wave
     float2* const leaf_stack = (WALK != WALK_REGS && (WALK != WALK_RUNTIME || ra.lds_leaf_stack))
         ? reinterpret_cast<float2*>(reinterpret_cast<char*>(g_lds) + ((sc.lds_bytes() + 15u) & ~15u)) + (threadIdx.x >> 6) * (64u * ra.leaf_slots) + lane
         : nullptr;
 
     // wave-uniform work cursor
-    uint32_t tile_x0 = 0, tile_row0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // cursor == items_per_batch: batch used up
+    uint32_t tile_x0 = 0, tile_row0 = 0, tile_slot0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // cursor == items_per_batch: batch used up
     bool exhausted = false;
 
     Path p;
     p.remain = 0u;
     bool has_path = false, stocked = false;
-    uint32_t out_idx = 0, stock_idx = 0;                                  // (sample - sample_begin) * n_pixels + pixel: < 2^32 (see streamed_chunk_spp)
+    uint32_t out_idx = 0, stock_idx = 0;                                  // radiance record of the sample (radiance_slot below): < 2^32 (see streamed_chunk_spp)
     Ray stock_ray;
     Rng stock_rng;
     uint32_t n_samples = 0, n_rays = 0;
@@ -82,6 +81,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                     ds0 = (b / n_tiles) * batch_spp;
                     tile_x0 = (tile % tiles_x) * 8u;
                     tile_row0 = (tile / tiles_x) * 8u;
+                    tile_slot0 = tile * n_spp * 64u;                                  // the tile's radiance records (radiance_slot)
                     items_per_batch = 64u * (n_spp - ds0 < batch_spp ? n_spp - ds0 : batch_spp);
                     cursor = 0;
                 }
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                         const uint32_t y = image_row(ra, row);
                         stock_rng = rng_seed(ra.seed_key, y * cam.width + x, ra.sample_begin + ds);
                         stock_ray = primary_ray(cam, x, y, stock_rng);
-                        stock_idx = ds * (uint32_t)n_pixels + row * cam.width + x;
+                        stock_idx = tile_slot0 + ds * 64u + l;
                         stocked = true;
                     }
                 }
@@ -176,13 +176,12 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
     const uint32_t lane = threadIdx.x & 63u;
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
     const uint32_t n_spp = ra.sample_end - ra.sample_begin;
-    const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
     char* const lds_tail = reinterpret_cast<char*>(g_lds) + ((sc.lds_bytes() + 15u) & ~15u);
     float2* const leaf_stack = reinterpret_cast<float2*>(lds_tail) + (threadIdx.x >> 6) * (64u * ra.leaf_slots) + lane;
     // the pool: field f of entry e at pool[f * 64 + e]
     uint32_t* const pool = reinterpret_cast<uint32_t*>(lds_tail + (size_t)THREADS * ra.leaf_slots * sizeof(float2)) + (threadIdx.x >> 6) * (64u * kPoolDwords);
 
-    uint32_t tile_x0 = 0, tile_row0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // wave-uniform work cursor
+    uint32_t tile_x0 = 0, tile_row0 = 0, tile_slot0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // wave-uniform work cursor
     uint32_t pool_head = 0, pool_count = 0;                                            // wave-uniform
     bool exhausted = false;
 
@@ -214,6 +213,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                     ds0 = (b / n_tiles) * batch_spp;
                     tile_x0 = (tile % tiles_x) * 8u;
                     tile_row0 = (tile / tiles_x) * 8u;
+                    tile_slot0 = tile * n_spp * 64u;
                     items_per_batch = 64u * (n_spp - ds0 < batch_spp ? n_spp - ds0 : batch_spp);
                     cursor = 0;
                 }
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                     pool[0u * 64u + e] = __float_as_uint(ray.o.x); pool[1u * 64u + e] = __float_as_uint(ray.o.y); pool[2u * 64u + e] = __float_as_uint(ray.o.z);
                     pool[3u * 64u + e] = __float_as_uint(ray.d.x); pool[4u * 64u + e] = __float_as_uint(ray.d.y); pool[5u * 64u + e] = __float_as_uint(ray.d.z);
                     pool[6u * 64u + e] = rng.s0; pool[7u * 64u + e] = rng.s1;
-                    pool[8u * 64u + e] = ds * (uint32_t)n_pixels + row * cam.width + x;
+                    pool[8u * 64u + e] = tile_slot0 + ds * 64u + lane;
                 }
                 pool_head = 0u;
                 pool_count = (uint32_t)__builtin_popcountll(vmask);
@@ -314,13 +314,12 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_dual_kernel(SceneDev scd
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
     const uint32_t n_spp = ra.sample_end - ra.sample_begin;
-    const unsigned long long n_pixels = (unsigned long long)ra.rows_local * cam.width;
     char* const lds_tail = reinterpret_cast<char*>(g_lds);
     float2* const stkA = reinterpret_cast<float2*>(lds_tail) + (2u * wave) * (64u * ra.leaf_slots) + lane;
     float2* const stkB = stkA + 64u * ra.leaf_slots;
     uint32_t* const pool = reinterpret_cast<uint32_t*>(lds_tail + (size_t)THREADS * 2u * ra.leaf_slots * sizeof(float2)) + wave * (64u * kPoolDwords);
 
-    uint32_t tile_x0 = 0, tile_row0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // wave-uniform work cursor
+    uint32_t tile_x0 = 0, tile_row0 = 0, tile_slot0 = 0, ds0 = 0, items_per_batch = 0, cursor = 0;    // wave-uniform work cursor
     uint32_t pool_head = 0, pool_count = 0;                                            // wave-uniform
     bool exhausted = false;
     uint32_t n_samples = 0, n_rays = 0;
@@ -344,6 +343,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_dual_kernel(SceneDev scd
                     ds0 = (b / n_tiles) * batch_spp;
                     tile_x0 = (tile % tiles_x) * 8u;
                     tile_row0 = (tile / tiles_x) * 8u;
+                    tile_slot0 = tile * n_spp * 64u;
                     items_per_batch = 64u * (n_spp - ds0 < batch_spp ? n_spp - ds0 : batch_spp);
                     cursor = 0;
                 }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_dual_kernel(SceneDev scd
                     pool[0u * 64u + e] = __float_as_uint(ray.o.x); pool[1u * 64u + e] = __float_as_uint(ray.o.y); pool[2u * 64u + e] = __float_as_uint(ray.o.z);
                     pool[3u * 64u + e] = __float_as_uint(ray.d.x); pool[4u * 64u + e] = __float_as_uint(ray.d.y); pool[5u * 64u + e] = __float_as_uint(ray.d.z);
                     pool[6u * 64u + e] = rng.s0; pool[7u * 64u + e] = rng.s1;
-                    pool[8u * 64u + e] = ds * (uint32_t)n_pixels + row * cam.width + x;
+                    pool[8u * 64u + e] = tile_slot0 + ds * 64u + lane;
                 }
                 pool_head = 0u;
                 pool_count = (uint32_t)__builtin_popcountll(vmask);
@@ -418,17 +418,24 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_dual_kernel(SceneDev scd
     flush_counters<false>(counters, n_samples, n_rays, ctr);
 }
 
-// pixels[idx] += color * (1/spp), samples in order (imager.rs:35,50)
-__global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restrict__ colors, float* __restrict__ accum,
-                                                          unsigned long long n_pixels, uint32_t n_spp, float inv_spp,
-                                                          uint32_t accumulate) {
-    const unsigned long long pix = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (pix >= n_pixels) return;
-    float* out = accum + 3ull * pix;
+// pixels[idx] += color * (1/spp), samples in order (imager.rs:35,50).
+// Radiance records are TILE-MAJOR (round 4): record (tile, sample, lane) at ((tile * n_spp + sample) * 64 + lane) x 12 bytes, tile = the 8x8-pixel
+// tile of the work batches, lane = (row % 8) * 8 + x % 8.  The 64 records of a tile and sample - what one wave finishes within one batch - are 768
+// contiguous bytes, twelve whole 64-byte lines that no other wave writes; in rounds 1-3 ([sample][pixel]) they were eight runs of 96 bytes, each
+// sharing its lines with neighbouring tiles that other waves finish at other times, and the L2 wrote the partial lines back: WRITE_SIZE 1.8x the
+// records' bytes on Cornell, 4.3x on the 100 k-sphere scene (profiles/r03_*_pmc.json).  The fold reads a tile-sample as one 768-byte wave load.
+__global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restrict__ colors, float* __restrict__ accum, uint32_t width, uint32_t rows,
+                                                          uint32_t tiles_x, uint32_t n_tiles, uint32_t n_spp, float inv_spp, uint32_t accumulate) {
+    const uint32_t tile = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (tile >= n_tiles) return;
+    const uint32_t x = (tile % tiles_x) * 8u + (lane & 7u), row = (tile / tiles_x) * 8u + (lane >> 3);
+    if (x >= width || row >= rows) return;                                      // an edge tile's off-image lanes: records never written, never read
+    float* out = accum + 3ull * ((unsigned long long)row * width + x);
     V3 acc = v3(0.0f, 0.0f, 0.0f);
     if (accumulate) acc = v3(out[0], out[1], out[2]);
+    const float* rec = colors + 3ull * ((unsigned long long)tile * n_spp * 64ull + lane);
     for (uint32_t s = 0; s < n_spp; s++) {
-        const Radiance c = *reinterpret_cast<const Radiance*>(colors + 3ull * ((unsigned long long)s * n_pixels + pix));      // one global_load_dwordx3
+        const Radiance c = *reinterpret_cast<const Radiance*>(rec + 3ull * 64ull * s);      // one global_load_dwordx3
         acc = acc + v3(c.r, c.g, c.b) * inv_spp;
     }
     out[0] = acc.x; out[1] = acc.y; out[2] = acc.z;
@@ -438,8 +445,11 @@ __global__ __launch_bounds__(256) void stream_fold_kernel(const float* __restric
 // Sized for 288 GB of HBM: a launch is a persistent grid that drains a batch queue, and its tail - the last waves finishing their longest
 // paths while the rest of the chip idles - is paid once per launch; the Cornell bench frame went from four 64-spp launches per 256-spp
 // step (4 GB) to one (+1.2 %), random-spheres 1080p from two to one (+2.6 %; profiles/r03_radiance_budget_sweep.txt).
+// Pixels of the 8x8 tiles that cover the image: the radiance buffer holds a record per tile lane (tile-major layout, stream_fold_kernel).
+static unsigned long long padded_pixels(uint32_t width, uint32_t rows) { return 64ull * ((width + 7u) / 8u) * ((rows + 7u) / 8u); }
+
 uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows, uint32_t radiance_gb) {
-    const unsigned long long px = (unsigned long long)width * rows;
+    const unsigned long long px = padded_pixels(width, rows);
     const unsigned long long budget = (unsigned long long)(radiance_gb >= 1u && radiance_gb <= 64u ? radiance_gb : 16u) << 30;
     const unsigned long long fit = px ? budget / (px * 12ull) : 256ull;
     uint32_t c = 16;
@@ -452,12 +462,12 @@ uint32_t streamed_chunk_spp(uint32_t width, uint32_t rows, uint32_t radiance_gb)
 constexpr size_t kWorkspaceHeader = 256;
 size_t streamed_workspace_bytes(uint32_t width, uint32_t rows, uint32_t samples, uint32_t radiance_gb) {
     const uint32_t chunk = streamed_chunk_spp(width, rows, radiance_gb);
-    return kWorkspaceHeader + (size_t)width * rows * (samples < chunk ? (samples ? samples : 1u) : chunk) * 3 * sizeof(float);
+    return kWorkspaceHeader + (size_t)padded_pixels(width, rows) * (samples < chunk ? (samples ? samples : 1u) : chunk) * 3 * sizeof(float);
 }
 // ... and the other way round: the samples per pixel a granted workspace holds (at most 256, and few enough for 32-bit record indices).
 // A render that was granted less than it asked for (device memory short: capi.hip halves the request) runs more, shorter launches.
 uint32_t streamed_chunk_that_fits(uint32_t width, uint32_t rows, size_t bytes) {
-    const unsigned long long px = (unsigned long long)width * rows;
+    const unsigned long long px = padded_pixels(width, rows);
     if (px == 0 || bytes <= kWorkspaceHeader) return 0;
     unsigned long long c = (bytes - kWorkspaceHeader) / (px * 12ull);
     if (c > 256ull) c = 256ull;
@@ -653,7 +663,6 @@ const char* streamed_kernel_name(const SceneLayout& L, const RenderArgs& ra, con
 hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const RenderArgs& ra_all, const trt_tuning& tn, void* workspace, size_t workspace_bytes,
                            float* d_accum, unsigned long long* d_counters, bool stats, hipStream_t stream) {
     if (ra_all.rows_local == 0 || cam.width == 0) return hipSuccess;
-    const unsigned long long n_pixels = (unsigned long long)ra_all.rows_local * cam.width;
     uint32_t* batch_counter = static_cast<uint32_t*>(workspace);                                     // layout: streamed_workspace_bytes
     float* colors = reinterpret_cast<float*>(static_cast<char*>(workspace) + kWorkspaceHeader);
     const uint32_t samples_all = ra_all.sample_end - ra_all.sample_begin;
@@ -712,9 +721,9 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         e = hipLaunchKernel(pl.kernel, dim3(grid_x), dim3((uint32_t)pl.threads), args, pl.lds_bytes, stream);
         timing_mark(stream, false);
         if (e != hipSuccess) return e;
-        const uint32_t fold_blocks = (uint32_t)((n_pixels + 255ull) / 256ull);
-        hipLaunchKernelGGL(stream_fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, colors, d_accum, n_pixels, ra.sample_end - ra.sample_begin,
-                           ra_all.inv_spp, (first && !ra_all.accumulate) ? 0u : 1u);
+        const uint32_t fold_blocks = (n_tiles + 3u) / 4u;                           // four tiles (waves) per workgroup
+        hipLaunchKernelGGL(stream_fold_kernel, dim3(fold_blocks), dim3(256), 0, stream, colors, d_accum, cam.width, ra_all.rows_local, tiles_x, n_tiles,
+                           ra.sample_end - ra.sample_begin, ra_all.inv_spp, (first && !ra_all.accumulate) ? 0u : 1u);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
         first = false;

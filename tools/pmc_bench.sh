@@ -26,7 +26,7 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("bench_module", "bench.py"); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
 base, tag = sys.argv[1], sys.argv[2]
 out = {}
-dominant = ("megakernel", "wavefront_kernel", "stream_sample_kernel", "stream_pool_kernel")
+dominant = ("megakernel", "wavefront_kernel", "stream_sample_kernel", "stream_pool_kernel", "stream_dual_kernel")
 for f in glob.glob(base + "/*/*/*_counter_collection.csv"):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
