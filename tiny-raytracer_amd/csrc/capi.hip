@@ -144,7 +144,7 @@ int fail_hip(hipError_t e, const char* what) {
 
 // The library defaults: the built-in values (kernels.h tuning_builtin, scene_host.cpp scene_options_builtin), overridden by the TRT_*
 // environment variables ONCE, when the first call needs them (a function-local static: initialised exactly once, thread-safe).  This is
-// the only place the library reads its environment; nothing on the launch path does (round 3 had 21 getenv calls there).
+// the only place the library reads its environment; nothing on the launch path does (round 3 read it in 21 places there).
 struct Defaults {
     trt_tuning tuning;
     trt_scene_options scene;

@@ -78,6 +78,7 @@ struct PhaseClock {
 template <bool STATS>
 struct Counters {
     uint32_t node = 0, sphere = 0, quad_plane = 0, quad_inside = 0, shade = 0;
+    uint32_t pend = 0;                                             // leaves put aside by the lock-step walk (diagnostic: tools/leaf_phase_budget.py)
     uint32_t w_rounds = 0, w_steps = 0, w_leaf = 0, w_gen = 0;     // wave-level trips, counted by the first active lane
 #ifdef TRT_PHASE_CLOCK
     PhaseClock clk;
@@ -547,6 +548,7 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
             if (__builtin_amdgcn_ballot_w64(top > limit) != 0ull) break;         // some lane could not hold another pair: test what is pending
         }
         TRT_CLK(ctr, 1);
+        if constexpr (STATS) ctr.pend += (uint32_t)(top - stk) >> 6;
         leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { trav_leaf<MODE, STATS>(sc, ray, tr, leaf, ctr); });
         TRT_CLK(ctr, 2);
     } while (i < n);
@@ -1034,10 +1036,10 @@ TRT_DEV void flush_counters(unsigned long long* counters, uint32_t samples, uint
     if (lane0) { for (int k = 0; k < 4; k++) atomicAdd(&counters[12 + k], (unsigned long long)ctr.clk.t[k]); }
 #endif
     if constexpr (STATS) {
-        uint32_t v[9] = {ctr.node, ctr.sphere, ctr.quad_plane, ctr.quad_inside, ctr.shade, ctr.w_rounds, ctr.w_steps, ctr.w_leaf, ctr.w_gen};
-        const int slot[9] = {CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_W_ROUNDS, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN};
+        uint32_t v[10] = {ctr.node, ctr.sphere, ctr.quad_plane, ctr.quad_inside, ctr.shade, ctr.w_rounds, ctr.w_steps, ctr.w_leaf, ctr.w_gen, ctr.pend};
+        const int slot[10] = {CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_W_ROUNDS, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_PEND};
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
+        for (int k = 0; k < 10; k++) {
             uint32_t t = wave_sum(v[k]);
             if (lane0 && t) atomicAdd(&counters[slot[k]], (unsigned long long)t);
         }
