@@ -313,6 +313,9 @@ TRT_DEV void trav_unpark(const float2* stk, Trav& tr) {
 // stragglers exit is one s_bcnt1 + compare.  Same operations on the same values as slab_fast_entry + the C++ loop body (min / max of
 // non-NaN values are exact, so their order is free); exec is restored on exit.  v48-v57 are fixed because a 128-bit LDS read needs four
 // consecutive registers and inline-asm operands cannot be taken apart.  Returns the lane's new stack top.
+// (Round 4 measured the LDS bank conflicts of the two ds_read_b128 - 22 % of the LDS index cycles - by keeping the nodes' two halves in two planes of
+// the LDS copy: conflicts 3.09 -> 1.80 G cycles per launch, launch 0.4 % SLOWER for the one extra address instruction per trip.  The conflicts cost less
+// than one vector instruction per box step: profiles/r04_lds_split_nodes_ab.txt, tools/archive/lds_split_nodes/.)
 #ifndef TRT_ASM_BOX_LOOP
 #define TRT_ASM_BOX_LOOP 1
 #endif
