@@ -2,7 +2,7 @@
 """One-off extended fuzz campaign (not collected by pytest): seeded random scenes of every size class - lock-step leaf list (<= 32
 primitives), LDS tree walk, 512-lane fallback, global-memory 16-byte-node walk - rendered by the default (streamed) backend and compared
 with the CPU oracle bit for bit, frame and ray count, until the time budget is spent.
-    python3 tests/fuzz_campaign.py [seconds=420] [first_seed=1000]
+    python3 tests/fuzz_campaign.py [seconds=420] [first_seed=1000] [tuning as JSON, e.g. '{"dual_walk": 1, "stream_waves_per_simd": 6}']
 Test infrastructure (it drives the oracle); the scenes are tests/test_gpu_fuzz.py's random_scene."""
 import os
 import sys
@@ -19,6 +19,8 @@ trt = importlib.import_module("tiny-raytracer_amd")
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 420.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+import json
+knobs = json.loads(sys.argv[3]) if len(sys.argv) > 3 else {}
 t0 = time.time()
 classes = [(1, 8), (9, 32), (33, 120), (121, 420), (421, 700), (1500, 4000)]
 done = rays = 0
@@ -35,6 +37,7 @@ while time.time() - t0 < budget:
     cpu, cst = orc.render(ow, ocam, spp, depth, desc["background"], seed=seed & 0xffff, nthreads=16)
     pw, pcam = trt.world_from_description(desc)
     r = trt.Renderer(spp, 1, depth, False, desc["background"], seed=seed & 0xffff)
+    r.tuning = knobs
     gpu = r.render(pcam, pw).data
     same = np.array_equal(np.ascontiguousarray(gpu, np.float32).view(np.uint32), np.ascontiguousarray(cpu, np.float32).view(np.uint32))
     if not same or r.last_stats["rays"] != cst["rays"]:
@@ -44,4 +47,4 @@ while time.time() - t0 < budget:
     if done % 50 == 0:
         print(f"{done} scenes, {rays} rays, {time.time() - t0:.0f} s", flush=True)
 print(f"fuzz campaign: {done} random scenes ({', '.join(f'{a}-{b} prims: {c}' for (a, b), c in zip(classes, per_class))}), {rays} rays, "
-      f"default backend == oracle bit for bit on every frame and ray count ({time.time() - t0:.0f} s)")
+      f"default backend{' with ' + json.dumps(knobs) if knobs else ''} == oracle bit for bit on every frame and ray count ({time.time() - t0:.0f} s)")
