@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where does the lock-step leaf list (walk_flat) stop paying?  Random closed-ish scenes of n primitives, streamed backend,
-TRT_FLAT_WALK=0 vs 1 (read when the scene is compiled)."""
+trt_scene_options.flat_walk = 0 vs 1 (read when the scene is compiled)."""
 import importlib
 import os
 import sys
@@ -32,9 +32,8 @@ def scene(n, seed=1):
 for n in (8, 16, 24, 32, 40, 48, 64):
     desc = scene(n)
     out = []
-    for flat in ("0", "1"):
-        os.environ["TRT_FLAT_WALK"] = flat
-        w, cam = trt.world_from_description(desc)
+    for flat in (0, 1):
+        w, cam = trt.world_from_description(desc, flat_walk=flat)
         r = trt.Renderer(64, 1, 20, False, desc["background"], seed=2, backend=trt.BACKEND_STREAMED)
         best = 0.0
         for rep in range(3):
