@@ -320,8 +320,8 @@ int workspace_acquire(trt_scene* s, int dev, size_t need, hipStream_t stream, Wo
             if (e == hipErrorOutOfMemory) {
                 // out of HBM for another copy: queue behind a running render whose buffer is large enough, if there is one; else the caller
                 // may ask for less (TRT_ERR_OOM: enqueue_render halves the samples per launch)
-                bool fits = false;
-                for (Workspace* w : dc.ws) fits = fits || w->bytes >= need;
+                bool fits = false;                                 // (a busy entry's fields belong to its owner: it may fit once released)
+                for (Workspace* w : dc.ws) fits = fits || w->busy || w->bytes >= need;
                 if (fits) { may_grow = false; continue; }
                 return fail(TRT_ERR_OOM, std::string(where) + ": " + hipGetErrorString(e));
             }
