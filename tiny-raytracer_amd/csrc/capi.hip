@@ -143,7 +143,7 @@ int fail_hip(hipError_t e, const char* what) {
     } while (0)
 
 // The library defaults: the built-in values (kernels.h tuning_builtin, scene_host.cpp scene_options_builtin), overridden by the TRT_*
-// environment variables ONCE, when the first call needs them (a function-local static: initialised exactly once, thread-safe).  This is
+// environment variables ONCE (a function-local static: initialised exactly once, thread-safe; first touched when the library is loaded).  This is
 // the only place the library reads its environment; nothing on the launch path does (round 3 read it in 21 places there).
 struct Defaults {
     trt_tuning tuning;
@@ -173,6 +173,9 @@ const Defaults& defaults() {
     }();
     return d;
 }
+
+// ... and that first need is the library's own load: a namespace-scope initialiser, so that "once, at load" holds whatever the host does later
+[[maybe_unused]] const bool g_defaults_read_at_load = (defaults(), true);
 
 int require_device() {
     int n = 0;
