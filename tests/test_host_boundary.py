@@ -449,3 +449,66 @@ def test_band_copy_plan_places_every_row_exactly_once(trt, height, ndev):
             written[pl.tail_frame_offset // row_bytes:] += 1
     assert np.all(written == 1)
     assert np.array_equal(frame.reshape(height, row_bytes)[:, 0], np.arange(height) % 251)
+
+
+# ---- round 4 (ABI v3): configuration as data ----
+def test_abi3_pod_layouts_match_the_c_compiler(trt, tmp_path):
+    """trt_tuning, trt_scene_options, trt_render_params (with its pointer member), trt_stats and trt_launch_plan as ctypes lays them out against
+    what gcc makes of include/tinyrt.h: sizes and the offsets that an alignment rule could move."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "tinyrt.h"\nint main(void) { printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", '
+                   'sizeof(trt_tuning), sizeof(trt_scene_options), offsetof(trt_scene_options, scratch_cap_bytes), sizeof(trt_render_params), '
+                   'offsetof(trt_render_params, tuning), sizeof(trt_stats), offsetof(trt_stats, gather_per_band), sizeof(trt_launch_plan), '
+                   'offsetof(trt_launch_plan, workspace_bytes)); return 0; }\n')
+    exe = str(tmp_path / "sz")
+    subprocess.run(["gcc", "-std=c11", "-I" + os.path.join(ROOT, "include"), str(src), "-o", exe], check=True)
+    got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
+    L = trt._lib
+    want = [C.sizeof(L.Tuning), C.sizeof(L.SceneOptions), L.SceneOptions.scratch_cap_bytes.offset, C.sizeof(L.RenderParams), L.RenderParams.tuning.offset,
+            C.sizeof(L.Stats), L.Stats.gather_per_band.offset, C.sizeof(L.LaunchPlan), L.LaunchPlan.workspace_bytes.offset]
+    assert got == want, (got, want)
+    assert C.sizeof(L.Tuning) == 96 and C.sizeof(L.SceneOptions) == 48
+
+
+def test_tuning_and_scene_option_defaults(trt):
+    """trt_tuning_default / trt_scene_options_default: the built-in values (kernels.h tuning_builtin; no TRT_* variable is set in the test environment),
+    unknown fields are refused by the Python mirror, and a render parameter block without a tuning is the NULL pointer."""
+    if any(k.startswith("TRT_") and k not in ("TRT_LIB_PATH", "TRT_BENCH_REHEARSAL") for k in os.environ):
+        pytest.skip("TRT_* variables are set: the library's defaults were overridden at load")
+    t = trt.tuning().as_dict()
+    assert (t["stream_batch_spp"], t["radiance_gb"], t["lds_leaf_stack"], t["ray_pool"], t["stragglers"], t["lds_stragglers"]) == (8, 16, 1, 1, 8, 8)
+    assert all(t[k] == 0 for k in ("stream_waves_per_simd", "stream_big_threads", "leaf_slots", "dual_walk", "runtime_walk", "xcd_remap",
+                                   "mega_waves_per_simd", "mega_threads", "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min"))
+    o = trt.scene_options()
+    assert abs(o.cull_prune - 0.5) < 1e-7 and (o.flat_walk, o.compact_nodes, o.top_nodes, o.scratch_cap_bytes) == (-1, -1, 0, 32 << 30)
+    with pytest.raises(TypeError):
+        trt.tuning(no_such_knob=1)
+    with pytest.raises(TypeError):
+        trt.scene_options(no_such_option=1)
+    r = trt.Renderer(4, 1, 8, False, (0, 0, 0))
+    assert not r.params().tuning                                             # NULL: the library's defaults
+    p = r.params(tuning={"stragglers": 3})
+    assert p.tuning and p.tuning.contents.stragglers == 3 and p.tuning.contents.radiance_gb == 16
+    w, _ = trt.world_from_description(trt.scenes.cornell(32, 32))
+    with pytest.raises(trt.TinyRTError):
+        w.get_bvh(cull_prune=0.0)                                            # must be in (0, 1]
+
+
+@pytest.mark.parametrize("options", [dict(cull_prune=0.9), dict(cull_prune=0.2), dict(flat_walk=0), dict(compact_nodes=1), dict(top_nodes=63),
+                                     dict(cull_prune=0.3, compact_nodes=1, flat_walk=1, top_nodes=31)])
+def test_scene_options_are_placement_only(trt, options):
+    """Whatever trt_scene_options say, the reference tree is the reference's node for node and the culling tree keeps the reference's leaf
+    sequence with the leaves' exact boxes - the two facts the bit-identical hits rest on; only inner nodes and layout move."""
+    for desc in (trt.scenes.cornell(32, 32), trt.scenes.random_spheres(32, 24), trt.scenes.sphere_grid(700, 32, 24)):
+        base, _ = trt.world_from_description(desc)
+        other, _ = trt.world_from_description(desc, **options)
+        b0, p0, s0 = base.get_bvh().nodes()
+        b1, p1, s1 = other.get_bvh().nodes()
+        assert np.array_equal(b0.view(np.uint32), b1.view(np.uint32)) and np.array_equal(p0, p1) and np.array_equal(s0, s1)
+        cb0, cp0, _ = base.get_bvh().cull_nodes()
+        cb1, cp1, _ = other.get_bvh().cull_nodes()
+        assert np.array_equal(cp0[cp0 >= 0], cp1[cp1 >= 0])                                       # same leaves, same order
+        assert np.array_equal(cb0[cp0 >= 0].view(np.uint32), cb1[cp1 >= 0].view(np.uint32))      # same leaf boxes
+        if options.get("compact_nodes") == 1:
+            assert other.get_bvh().compact_nodes() is not None                                    # forced on, whatever the scene's size
