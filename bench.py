@@ -183,7 +183,7 @@ def valu_roofline(key, avg_ms, rays_per_launch, warnings, single_gpu=True):
 
 OTHER_SCENES = (   # BASELINE configs[2] and configs[4] at their own sizes: short untimed-by-the-driver runs reported beside the headline
     ("random_spheres", 1920, 1080, 256, 3, 1),
-    ("sphere_grid", 3840, 2160, 16, 2, 1),
+    ("sphere_grid", 3840, 2160, 16, 3, 2),
 )
 
 

@@ -291,7 +291,8 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
 // The pool kernel for scenes in global memory with TWO paths per lane (rt_path.h walk_compact2): slot A and slot B of a lane are two
 // independent paths - each takes its primary rays from the wave's pool, walks, is shaded and stores its radiance exactly as the one
 // path of stream_pool_kernel does - and a round steps both walks in one loop that keeps two node loads in flight per wave.  LDS per
-// wave: two postponed-leaf stacks (slot A's, then slot B's) and the ray pool.  Which lane and which slot traces which sample
+// wave: two postponed-leaf stacks (slot A's, then slot B's) and the ray pool.  Opt-in (trt_tuning.dual_walk): measured +2 % at 6 waves per
+// SIMD and -7 % at 8 against the one-path kernel at 8 (rt_path.h box_loop_compact2 has the finding).  Which lane and which slot traces which sample
 // changes; no sample's radiance does (RNG keyed by pixel and sample, radiance stored per sample, folded in order).
 // ------------------------------------------------------------------------------------------------------------------
 struct DualSlot {
