@@ -283,3 +283,26 @@ def test_full_baseline_config_bit_identical_across_backends(trt):
     assert rays[0] == rays[1] and rays[0] > 1.2e11
     assert torch.equal(frames[0].view(torch.int32), frames[1].view(torch.int32))
     assert torch.isfinite(frames[0]).all() and 0.05 < float(frames[0].mean()) < 5.0
+
+
+@pytest.mark.parametrize("scene", ["cornell", "random_spheres", "grid4000"])
+def test_out_of_range_tunings_still_render_the_same_frame(trt, scene):
+    """trt_tuning is caller data: values outside every sensible range (ABI v3 took them out of the environment, where nobody typed 10^6) are
+    clamped by the library, never trusted by a launch - same frame, same ray count, no fault."""
+    desc = {"cornell": lambda: trt.scenes.cornell(160, 120), "random_spheres": lambda: trt.scenes.random_spheres(160, 90),
+            "grid4000": lambda: trt.scenes.sphere_grid(4000, 128, 72)}[scene]()
+    pw, pcam = trt.world_from_description(desc)
+    r = trt.Renderer(6, 1, 20, False, desc["background"], seed=2, backend=STREAMED)
+    ref = r.render(pcam, pw).data
+    rays = r.last_stats["rays"]
+    wild = [dict(stream_batch_spp=1), dict(stream_batch_spp=4000000000), dict(leaf_slots=100000, lds_leaf_stack=7), dict(stragglers=4000000000, lds_stragglers=99999),
+            dict(stream_waves_per_simd=99, stream_big_threads=123, ray_pool=77), dict(stream_waves_per_simd=1, radiance_gb=4000000000, runtime_walk=9),
+            dict(dual_walk=5, stream_waves_per_simd=3, leaf_slots=1), dict(dual_walk=1, stragglers=1000, stream_batch_spp=300),
+            {k: 4294967295 for k in trt.Tuning.FIELDS if k != "xcd_remap"}]
+    for knobs in wild:
+        got = r.render(pcam, pw, tuning=knobs).data
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and r.last_stats["rays"] == rays, knobs
+    for backend, knobs in ((0, dict(mega_waves_per_simd=4000000000, mega_threads=7, mega_global_waves8=3)), (1, dict(wf_waves_per_simd=12345, wf_serve_min=4000000000))):
+        rb = trt.Renderer(6, 1, 20, False, desc["background"], seed=2, backend=backend)
+        got = rb.render(pcam, pw, tuning=knobs).data
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)) and rb.last_stats["rays"] == rays, (backend, knobs)

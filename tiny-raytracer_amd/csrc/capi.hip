@@ -472,6 +472,11 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     ra.rows_local = rows;
     // scheduling (tinyrt.h trt_tuning): the caller's, else the library defaults; scheduling only, any value renders the same frame
     tn = p->tuning ? *p->tuning : defaults().tuning;
+    // whatever a caller writes into the knobs, the launch arithmetic stays in range (the launch plan clamps waves, lanes and slots itself)
+    if (tn.stream_batch_spp > 256u) tn.stream_batch_spp = 256u;      // a batch is at most one launch's samples of a tile
+    if (tn.stragglers > 63u) tn.stragglers = 63u;
+    if (tn.lds_stragglers > 63u) tn.lds_stragglers = 63u;
+    if (tn.radiance_gb > 64u) tn.radiance_gb = 64u;
     ra.leaf_slots = tn.leaf_slots;                         // rt_path.h walk_fast; 0 = the backend's default
     ra.lds_leaf_stack = tn.lds_leaf_stack;                 // 0 off, 1 where it costs no occupancy, 2 always
     ra.xcd_aware = tn.xcd_remap ? 1u : 0u;                 // off: contiguous image regions per XCD measured 2x slower (load imbalance)
