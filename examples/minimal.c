@@ -4,6 +4,7 @@
  * message when no MI355X is visible (the product has no CPU path). */
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "tinyrt.h"
 
@@ -40,6 +41,17 @@ int main(void) {
     trt_stats st;
     if (!accum || !rgb) return 1;
     CHECK(trt_render(scene, &camera, &p, accum, &st));                        /* Renderer::render */
+    /* Scheduling is data (ABI 3), like the reference's constructor arguments - never the environment.  Any value renders the SAME frame: */
+    trt_tuning tuning;
+    trt_tuning_default(&tuning);                                              /* the library's defaults ... */
+    tuning.stream_waves_per_simd = 5;                                         /* ... with another wave budget and leaf-stack depth */
+    tuning.leaf_slots = 3;
+    p.tuning = &tuning;
+    float *again = calloc((size_t)w * h * 3, sizeof(float));
+    if (!again) return 1;
+    CHECK(trt_render(scene, &camera, &p, again, NULL));
+    if (memcmp(accum, again, (size_t)w * h * 3 * sizeof(float)) != 0) { fprintf(stderr, "tuning changed the frame\n"); return 1; }
+    free(again);
     CHECK(trt_tonemap_u8(accum, w * h, 2.2f, rgb));                           /* Imager finalisation */
     FILE *f = fopen("minimal.ppm", "wb");
     if (!f) return 1;
