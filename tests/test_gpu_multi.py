@@ -268,3 +268,11 @@ def test_mixed_entry_points_from_eight_threads_on_two_scenes(trt):
             assert np.array_equal(bits(got[i]), bits(serial[i])), (rep, name)
         if rep == 1:
             trt._lib.check(trt.lib.trt_scene_trim(scene_c._h))            # frees every idle cached buffer; the next repetition re-grows them
+
+
+def test_minimal_c_example_renders_and_its_two_tunings_agree(trt, tmp_path):
+    """examples/minimal.c on the GPU: plain C11 against include/tinyrt.h, one render with the default tuning and one under another trt_tuning -
+    the program itself compares the two frames and exits non-zero if they differ."""
+    from test_host_boundary import test_header_is_valid_c_and_the_c_example_fails_loudly_without_gpu as build_and_run
+    assert trt.lib.trt_device_count() > 0
+    build_and_run(trt, tmp_path)
