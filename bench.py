@@ -4,7 +4,7 @@ hot path on the Cornell box at 2048x2048, depth 50 (BASELINE.json configs[3]; it
 kernel's roofline block (VALU lane-slot fraction: the binding resource; physical HBM traffic; SURVEY 8(d)'s algorithmic bytes,
 labelled) and the CPU oracle timed on this box's host cores (all cores and one thread).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE: starts the line below as a child and relays it)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of --spp-per-step samples per pixel over the whole image, continuing the running f32 sums that
@@ -232,7 +232,65 @@ def short_run(trt, torch, dev, scene_name, W, H, S, steps, warmup, depth, backen
     return out
 
 
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launcher_argv(n, port, bench_args, python=None):
+    """The command the driver's contract names for N > 1, built by the parent when `bench.py --gpus N` is started plainly."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(bench_args)
+
+
+def visible_gpus():
+    """Devices this process could use, WITHOUT initialising the GPU (torch.cuda.device_count() does not, on this image): the parent of
+    a self-launched run must stay a process that never touched the card."""
+    import torch
+    return torch.cuda.device_count()
+
+
+def self_launch(n, bench_args):
+    """`python3 bench.py --gpus N` with N > 1 and no WORLD_SIZE: start one rank per GPU under torch.distributed.run as a CHILD process
+    (never an exec), relay its stdout - rank 0's JSON line is the last line - and return its exit code.  Nothing here imports the
+    package, creates a HIP context or makes a GPU call."""
+    import subprocess
+    rehearsal = os.environ.get("TRT_BENCH_REHEARSAL") == "1"
+    have = visible_gpus()
+    if have < n and not rehearsal:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, this box shows {have} (TRT_BENCH_REHEARSAL=1 runs all ranks on cuda:0 over gloo: "
+              "a rehearsal, not a measurement)", file=sys.stderr, flush=True)
+        return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), TRT_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
+    cmd = launcher_argv(n, free_port(), bench_args)
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    last = None
+    for line in child.stdout:
+        line = line.rstrip("\n")
+        if line.startswith("{"):
+            if last is not None:
+                print(last, flush=True)
+            last = line                   # held back so that the JSON line is the LAST thing on stdout whatever else a rank prints
+        else:
+            print(line, flush=True)
+    rc = child.wait()
+    if last is not None:
+        print(last, flush=True)
+    return rc
+
+
 def main():
+    if "WORLD_SIZE" not in os.environ:
+        pre = argparse.ArgumentParser(add_help=False)
+        pre.add_argument("--gpus", type=int, default=1)
+        n = pre.parse_known_args()[0].gpus
+        if n > 1:
+            sys.exit(self_launch(n, sys.argv[1:]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
@@ -256,9 +314,7 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world_size != args.gpus:
-        if world_size == 1 and args.gpus > 1:
-            sys.exit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    if world_size != args.gpus:                        # under a launcher the launcher's world size is the truth
         args.gpus = world_size
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the product has no CPU path")
@@ -466,7 +522,11 @@ def main():
                                    f"{args.backend}, reference-order BVH, seed 1",
                        "rays": total_rays, "samples": total_samples, "image_rows_per_gpu": rows_local,
                        "parallelism": (f"image bands x{world_size}" + (" (REHEARSAL: all ranks on cuda:0, gloo)" if rehearsal else ""))
-                                      if world_size > 1 else "single GPU"},
+                                      if world_size > 1 else "single GPU",
+                       "world_size": dist.get_world_size() if world_size > 1 else 1,          # what the ranks saw, not what was asked for
+                       "collective_backend": (dist.get_backend() if world_size > 1 else None),
+                       "launched_by": "bench.py itself (child torch.distributed.run)" if os.environ.get("TRT_BENCH_SELF_LAUNCHED") == "1"
+                                      else ("external launcher" if world_size > 1 else "plain")},
             "roofline": roofline, "cpu_baseline": cpu, "parity": parity, "other_scenes": other,
         }
         if per_rank is not None:

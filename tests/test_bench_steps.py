@@ -81,3 +81,47 @@ def test_committed_pmc_profile_is_well_formed_and_staleness_is_reported(bench):
             stale.append(key)
     if stale:
         pytest.skip("PMC profile taken from other kernel sources (bench.py reports pmc_stale for them): " + ", ".join(stale))
+
+
+def test_plain_multi_gpu_command_builds_the_drivers_launcher_line(bench, monkeypatch):
+    """`python3 bench.py --gpus N --steps K --warmup W` (how the driver starts benches) with N > 1 and no WORLD_SIZE:
+    the parent builds exactly the contract's torch.distributed.run line around its own arguments and starts it as a child."""
+    import sys
+    argv = bench.launcher_argv(8, 29511, ["--gpus", "8", "--steps", "20", "--warmup", "5"], python="python3")
+    assert argv == ["python3", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                    "--master-port", "29511", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    # the child's stdout is relayed with rank 0's JSON line LAST; the exit code is the child's
+    started = {}
+
+    class FakeChild:
+        def __init__(self, cmd, **kw):
+            started["cmd"], started["kw"] = cmd, kw
+            self.stdout = iter(["rank chatter\n", '{"metric": "Mray/s"}\n', "late line from rank 3\n"])
+
+        def wait(self):
+            return 7
+
+    import subprocess
+    monkeypatch.setattr(subprocess, "Popen", FakeChild)
+    monkeypatch.setattr(bench, "visible_gpus", lambda: 4)
+    out = []
+    monkeypatch.setattr("builtins.print", lambda *a, **k: out.append((a, k.get("file"))))
+    assert bench.self_launch(4, ["--gpus", "4", "--steps", "3"]) == 7
+    assert started["cmd"][:4] == [sys.executable, "-m", "torch.distributed.run", "--nnodes=1"] and started["cmd"][4:6] == ["--nproc-per-node", "4"]
+    assert started["cmd"][-4:] == ["--gpus", "4", "--steps", "3"] and started["kw"]["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert [a[0] for a, f in out if f is None] == ["rank chatter", "late line from rank 3", '{"metric": "Mray/s"}']
+
+
+def test_plain_multi_gpu_command_without_the_gpus_exits_nonzero_with_one_line():
+    """Fewer visible devices than --gpus and no rehearsal flag: one clear line on stderr, a non-zero exit code, nothing started.
+    (This container has no GPU at all; the parent must get that far without importing the package or touching a device.)"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRT_BENCH_REHEARSAL")}
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has the GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and r.stdout == ""
+    assert len(r.stderr.strip().splitlines()) == 1 and "needs 2 visible GPUs" in r.stderr

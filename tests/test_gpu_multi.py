@@ -171,31 +171,67 @@ def test_kernel_timing_brackets_the_dominant_kernel(trt):
     assert n.value == 5 and 0.0 < ms.value < 1000.0
 
 
-def test_bench_n2_rehearsal_on_one_gpu():
-    """bench.py's N > 1 path (band layout per rank, kernel timing, counter all-reduce, gather + un-interleave, JSON line) with two
-    ranks on this one GPU over gloo (TRT_BENCH_REHEARSAL=1): everything the driver's multi-GPU run does except RCCL itself."""
+def _bench_line(cmd, env, root):
     import json
-    import os
-    import socket
     import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ, TRT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--width", "512", "--height", "500", "--spp-per-step", "64", "--cpu-seconds", "0"],
-                       capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
-    d = json.loads(line)
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert lines[-1].startswith("{"), "the JSON line is the last line of stdout"
+    return json.loads(lines[-1])
+
+
+BENCH_N2_ARGS = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--width", "512", "--height", "500", "--spp-per-step", "64", "--cpu-seconds", "0"]
+
+
+def _check_n2_line(d):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["unit"] == "Mray/s"
     assert d["config"]["samples"] == 3 * 64 * 512 * 500                 # both ranks' samples, every pixel once per sample
     assert d["config"]["image_rows_per_gpu"] == 256                     # 500 rows = 32 bands of 16 (the last one 4 rows): rank 0 owns 16 full bands
     assert "REHEARSAL" in d["config"]["parallelism"] and d["roofline"]["launches_per_step"] >= 1
+    assert d["config"]["world_size"] == 2 and d["config"]["collective_backend"] == "gloo"
+    assert len(d["roofline_per_rank"]) == 2
+
+
+def test_bench_n2_rehearsal_on_one_gpu():
+    """bench.py's N > 1 path (band layout per rank, kernel timing, counter all-reduce, gather + un-interleave, JSON line) with two
+    ranks on this one GPU over gloo (TRT_BENCH_REHEARSAL=1): everything the driver's multi-GPU run does except RCCL itself.
+    Started the way the DRIVER starts a bench - the plain command, no external launcher: the parent spawns
+    torch.distributed.run as a child before it touches the GPU and relays rank 0's line."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TRT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d = _bench_line([sys.executable, os.path.join(root, "bench.py")] + BENCH_N2_ARGS, env, root)
+    _check_n2_line(d)
+    assert "bench.py itself" in d["config"]["launched_by"]
+
+
+def test_bench_n2_rehearsal_under_an_external_launcher():
+    """The same run started by the launcher line of the build contract (python -m torch.distributed.run ... bench.py --gpus 2)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TRT_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    d = _bench_line(bench.launcher_argv(2, bench.free_port(), BENCH_N2_ARGS), env, root)
+    _check_n2_line(d)
+    assert d["config"]["launched_by"] == "external launcher"
+
+
+def test_bench_plain_n2_without_a_second_gpu_fails_with_one_line():
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this box has two GPUs: the plain command would run for real")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TRT_BENCH_REHEARSAL")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + BENCH_N2_ARGS, capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode != 0 and r.stdout.strip() == "" and "needs 2 visible GPUs" in r.stderr
 
 
 def test_multi_gpu_c_example_renders_identical_frames(tmp_path):
