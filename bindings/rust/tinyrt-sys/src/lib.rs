@@ -227,6 +227,7 @@ extern "C" {
     pub fn trt_world_add_material(w: *mut trt_world, name: *const c_char, m: *const trt_material) -> c_int;
     pub fn trt_world_get_material(w: *const trt_world, name: *const c_char, index: *mut u32) -> c_int;
     pub fn trt_world_add_sphere(w: *mut trt_world, center: trt_vec3, radius: f32, material: u32) -> c_int;
+    pub fn trt_world_add_spheres(w: *mut trt_world, n: u32, center_radius: *const f32, material: *const u32) -> c_int;
     pub fn trt_world_add_quad(w: *mut trt_world, corner: trt_vec3, u: trt_vec3, v: trt_vec3, material: u32) -> c_int;
     pub fn trt_world_num_geometries(w: *const trt_world) -> c_int;
     pub fn trt_world_num_materials(w: *const trt_world) -> c_int;

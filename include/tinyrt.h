@@ -72,6 +72,10 @@ int trt_world_add_material(trt_world *w, const char *name, const trt_material *m
 int trt_world_get_material(const trt_world *w, const char *name, uint32_t *index); /* World::get_material world.rs:35-41 */
 /* World::add_geometry(Box::new(Sphere::new(center, radius, material)))  world.rs:23-25, sphere.rs:16-26 */
 int trt_world_add_sphere(trt_world *w, trt_vec3 center, float radius, uint32_t material);
+/* The same for n spheres in array order - exactly the loop `for i in 0..n { world.add_geometry(Sphere::new(..)) }` (world.rs:23-25), one call
+ * instead of n for scenes of millions of primitives.  center_radius: 4n floats (x, y, z, radius); material: n indices.  All or nothing:
+ * an index out of range adds no sphere. */
+int trt_world_add_spheres(trt_world *w, uint32_t n, const float *center_radius, const uint32_t *material);
 /* World::add_geometry(Box::new(Quad::new(corner, u, v, material)))      world.rs:23-25, quad.rs:20-29 */
 int trt_world_add_quad(trt_world *w, trt_vec3 corner, trt_vec3 u, trt_vec3 v, uint32_t material);
 int trt_world_num_geometries(const trt_world *w);

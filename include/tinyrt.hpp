@@ -73,6 +73,8 @@ public:
         return idx;
     }
     void add_geometry(const Sphere& s) { invalidate(); check(trt_world_add_sphere(w_, s.center, s.radius, s.material)); }
+    // n spheres in array order: the loop of add_geometry(Sphere) in one call (center_radius: 4n floats x, y, z, r)
+    void add_spheres(uint32_t n, const float* center_radius, const uint32_t* material) { invalidate(); check(trt_world_add_spheres(w_, n, center_radius, material)); }
     void add_geometry(const Quad& q) { invalidate(); check(trt_world_add_quad(w_, q.corner, q.u, q.v, q.material)); }
     // new_box(a, b, material) of the reference binary (src/main.rs:89-125): six quads, same push order
     void add_box(Vec3 a, Vec3 b, MaterialHandle m) {

@@ -84,6 +84,7 @@ def _load():
         "orc_world_get_material": (C.c_int, [C.c_void_p, C.c_char_p]),
         "orc_world_add_sphere": (C.c_int, [C.c_void_p, Vec3, C.c_float, C.c_int]),
         "orc_world_add_quad": (C.c_int, [C.c_void_p, Vec3, Vec3, Vec3, C.c_int]),
+        "orc_world_add_spheres": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
         "orc_world_num_geometries": (C.c_int, [C.c_void_p]),
         "orc_world_build": (None, [C.c_void_p]),
         "orc_world_bvh_dump": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
@@ -156,6 +157,12 @@ class World:
             lib.orc_world_add_sphere(self._h, _v(geometry[1]), geometry[2], geometry[3])
         else:
             lib.orc_world_add_quad(self._h, _v(geometry[1]), _v(geometry[2]), _v(geometry[3]), geometry[4])
+
+    def add_spheres(self, center_radius, material):
+        cr = np.ascontiguousarray(center_radius, np.float32).reshape(-1, 4)
+        m = np.ascontiguousarray(material, np.int32).reshape(-1)
+        assert len(m) == len(cr)
+        lib.orc_world_add_spheres(self._h, len(cr), cr.ctypes.data, m.ctypes.data)
 
     def bvh_dump(self):
         n = 2 * lib.orc_world_num_geometries(self._h) - 1

@@ -558,6 +558,14 @@ static geometry *world_push_geo(orc_world *w) {
 }
 int orc_world_add_sphere(orc_world *w, orc_vec3 c, float r, int material) { sphere_init(world_push_geo(w), c, r, material); return w->ngeo - 1; }
 int orc_world_add_quad(orc_world *w, orc_vec3 corner, orc_vec3 u, orc_vec3 v, int material) { quad_init(world_push_geo(w), corner, u, v, material); return w->ngeo - 1; }
+/* n x World::add_geometry(Sphere::new(..)) in array order (world.rs:23-25): what a loop of orc_world_add_sphere does, for scenes of millions */
+int orc_world_add_spheres(orc_world *w, int n, const float *xyzr, const int32_t *material) {
+    for (int i = 0; i < n; i++) {
+        orc_vec3 c = {xyzr[4 * i], xyzr[4 * i + 1], xyzr[4 * i + 2]};
+        sphere_init(world_push_geo(w), c, xyzr[4 * i + 3], material[i]);
+    }
+    return w->ngeo;
+}
 int orc_world_num_geometries(const orc_world *w) { return w->ngeo; }
 
 void orc_world_build(orc_world *w) {                                                /* world.rs:43-45, bvh.rs:12-22 */

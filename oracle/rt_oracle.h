@@ -81,6 +81,7 @@ int orc_world_add_material(orc_world *, const char *name, int kind, orc_vec3 alb
 int orc_world_get_material(const orc_world *, const char *name);       /* -1 if absent */
 int orc_world_add_sphere(orc_world *, orc_vec3 center, float radius, int material);
 int orc_world_add_quad(orc_world *, orc_vec3 corner, orc_vec3 u, orc_vec3 v, int material);
+int orc_world_add_spheres(orc_world *, int n, const float *xyzr /* 4n */, const int32_t *material /* n */);   /* the loop of add_sphere, array order */
 int orc_world_num_geometries(const orc_world *);
 /* Build the BVH (World::get_bvh → BVH::new, bvh.rs:12-22,42-84).  Called lazily by render. */
 void orc_world_build(orc_world *);

@@ -115,6 +115,7 @@ SIGNATURES = {
     "trt_world_add_material": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(Material)]),
     "trt_world_get_material": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32)]),
     "trt_world_add_sphere": (C.c_int, [C.c_void_p, Vec3, C.c_float, C.c_uint32]),
+    "trt_world_add_spheres": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "trt_world_add_quad": (C.c_int, [C.c_void_p, Vec3, Vec3, Vec3, C.c_uint32]),
     "trt_world_num_geometries": (C.c_int, [C.c_void_p]),
     "trt_world_num_materials": (C.c_int, [C.c_void_p]),

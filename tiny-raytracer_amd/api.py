@@ -168,6 +168,15 @@ class World:
         else:
             raise TypeError("geometry must be a Sphere or a Quad")
 
+    def add_spheres(self, center_radius, material):
+        """n x add_geometry(Sphere(...)) in array order, one call: center_radius float32 [n, 4] (x, y, z, radius), material uint32 [n]."""
+        self._scene = None
+        cr = np.ascontiguousarray(center_radius, np.float32).reshape(-1, 4)
+        m = np.ascontiguousarray(material, np.uint32).reshape(-1)
+        if len(m) != len(cr):
+            raise ValueError("one material index per sphere")
+        check(lib.trt_world_add_spheres(self._h, len(cr), cr.ctypes.data, m.ctypes.data))
+
     def num_geometries(self):
         return lib.trt_world_num_geometries(self._h)
 

@@ -610,6 +610,23 @@ int trt_world_add_sphere(trt_world* w, trt_vec3 center, float radius, uint32_t m
     }
     return TRT_OK;
 }
+int trt_world_add_spheres(trt_world* w, uint32_t n, const float* center_radius, const uint32_t* material) {
+    if (!w) return fail(TRT_ERR_INVALID_ARG, "world is null");
+    if (n == 0) return TRT_OK;
+    if (!center_radius || !material) return fail(TRT_ERR_INVALID_ARG, "null array");
+    for (uint32_t i = 0; i < n; i++)
+        if (material[i] >= w->w.materials.size()) return fail(TRT_ERR_INVALID_ARG, "material index out of range");      // nothing is added then
+    try {
+        w->w.geometries.reserve(w->w.geometries.size() + n);
+        for (uint32_t i = 0; i < n; i++) {
+            const float* c = center_radius + 4u * (size_t)i;
+            w->w.geometries.push_back(Geometry{0u, material[i], trt_vec3{c[0], c[1], c[2]}, trt_vec3{c[3], 0.0f, 0.0f}, trt_vec3{0.0f, 0.0f, 0.0f}});
+        }
+    } catch (const std::bad_alloc&) {
+        return fail(TRT_ERR_OOM, "out of memory");
+    }
+    return TRT_OK;
+}
 int trt_world_add_quad(trt_world* w, trt_vec3 corner, trt_vec3 u, trt_vec3 v, uint32_t material) {
     if (!w) return fail(TRT_ERR_INVALID_ARG, "world is null");
     if (material >= w->w.materials.size()) return fail(TRT_ERR_INVALID_ARG, "material index out of range");

@@ -165,9 +165,64 @@ def sphere_grid(n=100000, width=3840, height=2160, seed=43):
     return dict(name="sphere_grid_%d" % n, materials=mats, geometries=geos, camera=cam, background=(0.7, 0.8, 1.0))
 
 
+def _mix32(x):
+    """lowbias32 on a numpy uint32 array (scene layout only)."""
+    import numpy as np
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x *= np.uint32(0x7FEB352D)
+    x ^= x >> np.uint32(15)
+    x *= np.uint32(0x846CA68B)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def sphere_field(n=4_000_000, width=3840, height=2160, seed=44, palette=4096):
+    """The deep-BVH scene (sphere_grid, BASELINE config 5) at sizes BEYOND the 256 MiB Infinity Cache: n spheres of radius 0.2 uniformly
+    scattered over a sqrt(n) x sqrt(n) square at y = 0.2 + the ground sphere, same camera recipe and material mix (80 % Lambertian,
+    15 % Metal, 5 % Dielectric) drawn from a palette of `palette` materials.  Build-defined like sphere_grid; generated with numpy from a
+    counter-based hash (sphere i's values depend on (seed, i) only), and handed over as ARRAYS: `bulk_spheres` = (float32 [n, 4] centre +
+    radius, material NAME index into `materials`) which build_world adds through World.add_spheres - one call instead of n."""
+    import numpy as np
+    side = math.sqrt(n)
+    half = side / 2.0
+    rng = _Lcg(seed)
+    mats = [("ground", LAMBERTIAN, (0.5, 0.5, 0.5), 0.0)]
+    for i in range(palette):
+        _sphere_material(rng, i, mats)
+    i = np.arange(n, dtype=np.uint32)
+    key = np.uint32((seed * 2654435761) & 0xFFFFFFFF)
+
+    def u01(salt):
+        return (_mix32(i * np.uint32(3) + np.uint32(salt) + key) >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+    cr = np.empty((n, 4), np.float32)
+    cr[:, 0] = np.float32(-half) + np.float32(2.0 * half) * u01(0)
+    cr[:, 1] = np.float32(0.2)
+    cr[:, 2] = np.float32(-half) + np.float32(2.0 * half) * u01(1)
+    cr[:, 3] = np.float32(0.2)
+    mat = (np.uint32(1) + _mix32(i * np.uint32(3) + np.uint32(2) + key) % np.uint32(palette)).astype(np.uint32)      # index into mats (0 = ground)
+    d = _f32(0.12 * side)
+    cam = dict(focus_distance=_f32(math.sqrt(3.0) * d), defocus_angle=0.0, position=(d, _f32(0.5 * d), d),
+               look_at=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), vertical_fov=35.0, width=width, height=height)
+    return dict(name="sphere_field_%d" % n, materials=mats, geometries=[("sphere", (0.0, -1000.0, 0.0), 1000.0, "ground")],
+                bulk_spheres=(cr, mat), camera=cam, background=(0.7, 0.8, 1.0))
+
+
 def build_world(desc, world, material_ctor, sphere_ctor, quad_ctor):
     """Feed a description to a World-like object.  material_ctor(kind, albedo, param) -> material value;
-    sphere_ctor/quad_ctor build geometry values from (…, material handle)."""
+    sphere_ctor/quad_ctor build geometry values from (…, material handle).  `bulk_spheres` (sphere_field) follow the listed geometries,
+    in array order, through world.add_spheres."""
+    _build_world_listed(desc, world, material_ctor, sphere_ctor, quad_ctor)
+    if desc.get("bulk_spheres") is not None:
+        import numpy as np
+        cr, mat_pos = desc["bulk_spheres"]
+        handle_of = np.array([world.get_material(m[0]) for m in desc["materials"]], dtype=np.uint32)      # position in `materials` -> world handle
+        world.add_spheres(cr, handle_of[mat_pos])
+    return world
+
+
+def _build_world_listed(desc, world, material_ctor, sphere_ctor, quad_ctor):
     for name, kind, albedo, param in desc["materials"]:
         world.add_material(name, material_ctor(kind, albedo, param))
     handles = {}
