@@ -301,7 +301,9 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--height", type=int, default=2048)
     ap.add_argument("--depth", type=int, default=50)
-    ap.add_argument("--scene", default="cornell", choices=["cornell", "random_spheres", "sphere_grid"])
+    ap.add_argument("--scene", default="cornell", choices=["cornell", "random_spheres", "sphere_grid", "sphere_field"])
+    ap.add_argument("--spheres", type=int, default=0, help="sphere_grid (default 100000) / sphere_field (default 4000000): number of spheres")
+    ap.add_argument("--tuning", default="", help="trt_tuning fields for the timed renders, e.g. dual_walk=1,stream_waves_per_simd=6 (scheduling only)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="budget of the cpu_baseline leg; 0 = measurement only: no CPU leg, no parity block, no other scenes (what the tools/ scripts use)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the untimed counter pass")
@@ -338,10 +340,13 @@ def main():
     trt._lib.check(trt.lib.trt_set_device(local_rank))
 
     W, H = args.width, args.height
+    t_scene = time.perf_counter()
     desc = {"cornell": trt.scenes.cornell, "random_spheres": trt.scenes.random_spheres,
-            "sphere_grid": lambda w, h: trt.scenes.sphere_grid(int(os.environ.get("TRT_BENCH_SPHERES", "100000")), w, h)}[args.scene](W, H)
+            "sphere_grid": lambda w, h: trt.scenes.sphere_grid(args.spheres or int(os.environ.get("TRT_BENCH_SPHERES", "100000")), w, h),
+            "sphere_field": lambda w, h: trt.scenes.sphere_field(args.spheres or 4_000_000, w, h)}[args.scene](W, H)
     world, cam = trt.world_from_description(desc)
     scene = world.get_bvh()
+    t_scene = time.perf_counter() - t_scene
     total_spp = FRAME_SPP
     try:
         step_range(0, args.spp_per_step)
@@ -351,6 +356,8 @@ def main():
         args.backend = "streamed"
     backend = {"wavefront": trt.BACKEND_WAVEFRONT, "streamed": trt.BACKEND_STREAMED}.get(args.backend, trt.BACKEND_MEGAKERNEL)
     renderer = trt.Renderer(total_spp, 1, args.depth, False, desc["background"], seed=1, backend=backend)
+    if args.tuning:
+        renderer.tuning = {k: int(v) for k, v in (kv.split("=") for kv in args.tuning.split(","))}
     kernel_name = trt.lib.trt_dominant_kernel(scene._h, C.byref(cam.pod), C.byref(renderer.params())).decode()      # what a kernel trace of a step shows
 
     lay = tiles.band_layout(H, world_size, rank)
@@ -434,7 +441,8 @@ def main():
     avg_ms = k_ms.value / n_launch if n_launch else None
     my_rays = int(ctr[1].item())
     rays_per_launch = my_rays / n_launch if n_launch else 0.0
-    key = f"{args.scene}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}"
+    scene_tag = args.scene + (str(args.spheres) if args.spheres else "")
+    key = f"{scene_tag}_{W}x{H}_d{args.depth}_spp{S}_{args.backend}" + ("_" + args.tuning.replace(",", "_").replace("=", "") if args.tuning else "")
     roofline = {"bound": "valu", "kernel": kernel_name, "achieved": None, "peak": round(VALU_PEAK_GINST * 64.0 / 1e3, 2),
                 "unit": "T f32 lane-instructions/s (VALU wave-instructions x active lanes)", "frac": None, "traffic": None,
                 "frac_is": "lane-slot fraction: VALU lane-instructions per second / (1024 SIMDs x 2.4 GHz / 2 cycles x 64 lanes); "
@@ -521,6 +529,7 @@ def main():
             "config": {"workload": f"{args.scene} {W}x{H}, depth {args.depth}, {S} spp per step (of 4096), "
                                    f"{args.backend}, reference-order BVH, seed 1",
                        "rays": total_rays, "samples": total_samples, "image_rows_per_gpu": rows_local,
+                       "scene_build_s": round(t_scene, 2), "scene": scene.info(), "tuning": args.tuning or "default",
                        "parallelism": (f"image bands x{world_size}" + (" (REHEARSAL: all ranks on cuda:0, gloo)" if rehearsal else ""))
                                       if world_size > 1 else "single GPU",
                        "world_size": dist.get_world_size() if world_size > 1 else 1,          # what the ranks saw, not what was asked for
