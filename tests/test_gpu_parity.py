@@ -239,6 +239,43 @@ def test_degenerate_rays_take_the_exact_slab_path(trt, orc):
         assert gst[k] == ost[k], k
 
 
+@pytest.mark.parametrize("scene", ["cornell", "random_spheres", "sphere_grid"])
+def test_nan_rays_hit_nothing_without_walking(trt, orc, scene):
+    """A NaN anywhere in a ray's origin or direction: the reference walks every box the NaN lets through and finds nothing (every primitive
+    test fails on a NaN t: sphere.rs:40,42, quad.rs:37).  The production walk answers "miss" at once (rt_path.h ray_has_nan; round 5: such
+    rays - one Lambertian scatter in 2^23 - each held a wave for a whole-tree walk); the counting walk still performs the reference's tests.
+    All three give the same colours; the counting walk's counters equal the oracle's."""
+    desc = {"cornell": lambda: trt.scenes.cornell(8, 8), "random_spheres": lambda: trt.scenes.random_spheres(8, 8),
+            "sphere_grid": lambda: trt.scenes.sphere_grid(3000, 8, 8)}[scene]()
+    pw, _ = trt.world_from_description(desc)
+    ow, _ = orc.world_from_description(desc)
+    nan = float("nan")
+    o0 = desc["camera"]["position"]
+    good_d = (-0.6, -0.3, -0.74) if scene != "cornell" else (0.0, 0.0, 1.0)
+    rays = [(o0, good_d)]                                                  # a sane ray among them
+    for k in range(1, 8):                                                  # every non-empty subset of NaN direction components
+        rays.append((o0, tuple(nan if k >> a & 1 else good_d[a] for a in range(3))))
+    for k in range(1, 8):                                                  # ... and of NaN origin components
+        rays.append((tuple(nan if k >> a & 1 else o0[a] for a in range(3)), good_d))
+    rays.append(((nan, nan, nan), (nan, nan, nan)))
+    rays.append((o0, (-nan, 0.0, 1.0)))
+    n = len(rays)
+    gp, op = (trt.SamplePoint * n)(), (orc.SamplePoint * n)()
+    for i, (o, d) in enumerate(rays):
+        op[i].x, op[i].y = i, 2
+        op[i].ray = orc.Ray(orc.Vec3(*o), orc.Vec3(*d))                  # used as given (not re-normalised)
+        C.memmove(C.byref(gp[i]), C.byref(op[i]), 32)
+    bg = (0.1, 0.2, 0.3)
+    counted, gst = trt.sample_batch(pw.get_bvh(), gp, 6, bg, seed=9)
+    fast, _ = trt.sample_batch(pw.get_bvh(), gp, 6, bg, seed=9, collect_stats=False)
+    oout, ost = orc.sample_batch(ow, op, 6, bg, seed=9)
+    assert bytes(counted) == bytes(oout) and bytes(fast) == bytes(oout)
+    for k in STAT_KEYS:
+        assert gst[k] == ost[k], k
+    for i in range(1, n):                                                  # a NaN ray sees the background, unattenuated
+        assert oout[i].color.tolist() == [np.float32(c) for c in bg], i
+
+
 def test_sample_batch_empty_and_zero_budget(trt):
     pw, _ = trt.world_from_description(trt.scenes.cornell(8, 8))
     out, st = trt.sample_batch(pw.get_bvh(), (trt.SamplePoint * 0)(), 4, (0, 0, 0))

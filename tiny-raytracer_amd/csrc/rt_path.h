@@ -190,10 +190,26 @@ TRT_DEV void trav_leaf(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, uint3
     }
 }
 
+// A ray with a NaN in its origin or direction hits NOTHING in the reference, whatever the scene: Sphere::hit forms `a = d.d`, `half_b = oc.d`
+// (sphere.rs:31-34) - one of them is NaN, so is the discriminant, `disc < 0` is false, both roots are NaN and `Range::contains` (sphere.rs:40,42)
+// is false for NaN; Quad::hit's `t = (d - o.n) / (dir.n)` (quad.rs:34-37) is NaN and fails the same `contains`.  Meanwhile every slab the NaN
+// reaches PASSES (aabb.rs:36-61: comparisons with NaN are false, so start / end keep their values), so the reference walks the tree - ALL of it
+// when the whole direction is NaN, which is the usual case: `normal + random_unit_vector()` with u3 = 0 normalises a zero vector (vec3extend.rs:
+// 16-34; one Lambertian scatter in 2^23) - to find nothing: 2N - 1 box tests and N primitive tests by ONE lane while its wave's other 63 wait.
+// Harmless at 18 quads; at 100 k spheres ~70 such rays per 16-spp launch of 3840x2160 each held a wave for tens of milliseconds, and at 4 M
+// spheres they WERE the launch (4.8 s of a 4.8 s launch: 2.8 % of the wave slots occupied, profiles/r05_nan_rays_tail.txt).  The production
+// kernels therefore answer "miss" at once; the counting kernels (STATS) still walk, because their counters are compared with the oracle's.
+TRT_DEV bool ray_has_nan(const Ray& r) {
+    return !(r.o.x == r.o.x) | !(r.o.y == r.o.y) | !(r.o.z == r.o.z) | !(r.d.x == r.d.x) | !(r.d.y == r.d.y) | !(r.d.z == r.d.z);
+}
+
 // The rare walks: reference tree (counting kernels) and rays whose slab arithmetic needs the reference's
 // compare-and-assign form.  Runs the walk `tr` to its end.
 template <int MODE, bool STATS>
 TRT_DEV void closest_hit_ref(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr) {
+    if constexpr (!STATS) {
+        if (ray_has_nan(ray)) { tr.i = tr.n; return; }              // nothing can be hit (see ray_has_nan): t_best = inf, prim_best = PRIM_NONE
+    }
     for (;;) {
         uint32_t leaf = PRIM_NONE;
         while (tr.i < tr.n) {

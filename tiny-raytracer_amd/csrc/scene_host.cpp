@@ -10,7 +10,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <thread>
 
 namespace trt {
 namespace {
@@ -54,46 +56,86 @@ inline int32_t total_order_key(float f) {
 
 inline float bitsf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 
+// Node::new (bvh.rs:42-84) over `objs`, nodes in pre-order.  A subtree over n primitives has exactly 2n - 1 nodes (one primitive per leaf), so
+// every node's index is known before its subtree is built: node `me` over n objects has its left child at me + 1 (mid = n / 2 objects, 2 mid - 1
+// nodes) and its right child at me + 2 mid.  The arrays are sized up front and the two halves of the top levels are built by different threads
+// (they write disjoint index ranges).  The reference's `sort_by(total_cmp of bbox.min[axis])` is a STABLE sort of the objects in the order the
+// parent handed them over; here: one u64 per object, (order-preserving key << 32) | position in the incoming order, and a plain sort of those -
+// equal keys stay in incoming order, which is what a stable sort does, without an indirect comparison per step (round 5: 4 M spheres in
+// seconds instead of most of a minute).
 struct Builder {
     const std::vector<Box>& prim_box;
     std::vector<Box> node_box;
     std::vector<int32_t> node_prim;
     std::vector<int32_t> node_skip;
-    uint32_t max_depth = 0;
+    std::atomic<uint32_t> max_depth{0};
 
-    explicit Builder(const std::vector<Box>& pb) : prim_box(pb) {}
+    explicit Builder(const std::vector<Box>& pb) : prim_box(pb) {
+        const size_t nn = 2 * pb.size() - 1;
+        node_box.resize(nn);
+        node_prim.assign(nn, -1);
+        node_skip.assign(nn, 0);
+    }
 
-    // Node::new (bvh.rs:42-84), emitting nodes in pre-order.  Returns the node's index.
-    uint32_t build(const uint32_t* objs, size_t n, uint32_t depth) {
-        uint32_t me = (uint32_t)node_box.size();
-        node_box.push_back(Box{});
-        node_prim.push_back(-1);
-        node_skip.push_back(0);
-        if (depth > max_depth) max_depth = depth;
+    void note_depth(uint32_t depth) {
+        uint32_t seen = max_depth.load(std::memory_order_relaxed);
+        while (depth > seen && !max_depth.compare_exchange_weak(seen, depth, std::memory_order_relaxed)) {}
+    }
+
+    // `objs`: this node's objects in the order the parent hands them over; reordered in place (the reference sorts a copy that only
+    // its own subtree sees: same thing).  `threads`: how many threads this subtree may still use.
+    void build(uint32_t me, uint32_t* objs, size_t n, uint32_t depth, unsigned threads) {
         if (n == 1) {
+            note_depth(depth);
             node_box[me] = prim_box[objs[0]];
             node_prim[me] = (int32_t)objs[0];
         } else if (n == 2) {                     // children keep the given order: no sort (bvh.rs:58-67)
-            uint32_t l = build(objs, 1, depth + 1);
-            uint32_t r = build(objs + 1, 1, depth + 1);
-            node_box[me] = box_union(node_box[l], node_box[r]);
+            note_depth(depth + 1);
+            node_box[me + 1] = prim_box[objs[0]]; node_prim[me + 1] = (int32_t)objs[0]; node_skip[me + 1] = (int32_t)me + 2;
+            node_box[me + 2] = prim_box[objs[1]]; node_prim[me + 2] = (int32_t)objs[1]; node_skip[me + 2] = (int32_t)me + 3;
+            node_box[me] = box_union(node_box[me + 1], node_box[me + 2]);
         } else {
             Box all = prim_box[objs[0]];
             for (size_t i = 1; i < n; i++) all = box_union(all, prim_box[objs[i]]);
-            int axis = box_longest_axis(all);
-            std::vector<uint32_t> sorted(objs, objs + n);
-            std::stable_sort(sorted.begin(), sorted.end(), [&](uint32_t a, uint32_t b) {
-                return total_order_key(axis_of(prim_box[a].lo, axis)) < total_order_key(axis_of(prim_box[b].lo, axis));
-            });
-            size_t mid = n / 2;
-            uint32_t l = build(sorted.data(), mid, depth + 1);
-            uint32_t r = build(sorted.data() + mid, n - mid, depth + 1);
+            const int axis = box_longest_axis(all);
+            {
+                constexpr size_t kSmall = 64;                               // most nodes are small: no heap traffic for them
+                uint64_t keyed_small[kSmall];
+                uint32_t in_small[kSmall];
+                std::vector<uint64_t> keyed_big;
+                std::vector<uint32_t> in_big;
+                uint64_t* keyed = keyed_small;
+                uint32_t* in = in_small;
+                if (n > kSmall) { keyed_big.resize(n); in_big.resize(n); keyed = keyed_big.data(); in = in_big.data(); }
+                for (size_t i = 0; i < n; i++) {
+                    const uint32_t k = (uint32_t)total_order_key(axis_of(prim_box[objs[i]].lo, axis)) ^ 0x80000000u;    // signed order -> unsigned order
+                    keyed[i] = (uint64_t)k << 32 | (uint64_t)i;
+                    in[i] = objs[i];
+                }
+                std::sort(keyed, keyed + n);
+                for (size_t i = 0; i < n; i++) objs[i] = in[(uint32_t)keyed[i]];
+            }
+            const size_t mid = n / 2;
+            const uint32_t l = me + 1, r = me + 2 * (uint32_t)mid;
+            if (threads > 1 && n >= 32768) {
+                const unsigned tl = threads / 2, tr = threads - tl;
+                std::thread left([&] { build(l, objs, mid, depth + 1, tl); });
+                build(r, objs + mid, n - mid, depth + 1, tr);
+                left.join();
+            } else {
+                build(l, objs, mid, depth + 1, 1);
+                build(r, objs + mid, n - mid, depth + 1, 1);
+            }
             node_box[me] = box_union(node_box[l], node_box[r]);
         }
-        node_skip[me] = (int32_t)node_box.size();
-        return me;
+        node_skip[me] = (int32_t)(me + 2 * (uint32_t)n - 1);
     }
 };
+
+inline unsigned host_threads() {
+    const unsigned hc = std::thread::hardware_concurrency();
+    return hc == 0 ? 1u : (hc > 16u ? 16u : hc);
+}
 
 inline bool tame(float v) { return fabsf(v) < 1e30f; }
 inline bool tame3(H3 v) { return tame(v.x) && tame(v.y) && tame(v.z); }
@@ -160,53 +202,112 @@ struct CullBuilder {
     double kPrune;                           // trt_scene_options.cull_prune: 0.5 measured best on MI355X (round 3, profiles/r03_defaults_sweep.txt: random-spheres
                                              // 0.4-0.5 beat 0.7 by 3 %, the 100 k-sphere scene is flat from 0.3 to 0.7); any value gives the same hits
     const std::vector<Box>& leaf_box;        // leaf k of the reference tree, in left-first order
+    // the finished tree, pre-order; a skip link is the index of the node to go to when the subtree is done
     std::vector<Box> node_box;
     std::vector<int32_t> node_leaf;          // leaf sequence number or -1
     std::vector<int32_t> node_skip;
 
     CullBuilder(const std::vector<Box>& lb, double prune) : kPrune(prune), leaf_box(lb) {}
 
+    // A subtree in its own arrays, indices relative to its first node (so that subtrees built by different threads can be concatenated)
+    struct Part {
+        std::vector<Box> box;
+        std::vector<int32_t> leaf, skip;
+        void append(const Part& p) {
+            const int32_t base = (int32_t)box.size();
+            box.insert(box.end(), p.box.begin(), p.box.end());
+            leaf.insert(leaf.end(), p.leaf.begin(), p.leaf.end());
+            skip.reserve(skip.size() + p.skip.size());
+            for (int32_t s : p.skip) skip.push_back(s + base);
+        }
+    };
     struct Frame { uint32_t a, b; double parent_sa; int32_t node; bool close; };
+    struct Split { Box all; double sa; bool emit; uint32_t k; };
 
-    void build() {
-        const uint32_t n = (uint32_t)leaf_box.size();
+    // One node: the box of leaves [a, b), whether it is emitted under an emitted ancestor of area `parent_sa`, and its best split
+    // by SAH over the fixed order (prefix boxes on the fly, suffix boxes precomputed).  m = b - a >= 2 for the split.
+    Split split(uint32_t a, uint32_t b, double parent_sa, std::vector<Box>& suffix) const {
+        Split r;
+        const uint32_t m = b - a;
+        r.all = leaf_box[a];
+        for (uint32_t k = a + 1; k < b; k++) r.all = box_union(r.all, leaf_box[k]);
+        r.sa = surface_area(r.all);
+        r.emit = m == 1 || parent_sa < 0.0 || r.sa < kPrune * parent_sa;
+        r.k = 1;
+        if (m == 1) return r;
+        suffix.resize(m);
+        suffix[m - 1] = leaf_box[b - 1];
+        for (uint32_t k = m - 1; k-- > 0;) suffix[k] = box_union(leaf_box[a + k], suffix[k + 1]);
+        Box prefix = leaf_box[a];
+        double best = 0.0;
+        for (uint32_t k = 1; k < m; k++) {           // left = [a, a+k), right = [a+k, b)
+            const double c = surface_area(prefix) * k + surface_area(suffix[k]) * (m - k);
+            if (k == 1 || c < best) { best = c; r.k = k; }
+            prefix = box_union(prefix, leaf_box[a + k]);
+        }
+        return r;
+    }
+
+    // leaves [a0, b0) into `out`, one thread
+    void build_serial(uint32_t a0, uint32_t b0, double parent_sa0, Part& out) const {
         std::vector<Frame> stack;
         std::vector<Box> suffix;
-        stack.push_back(Frame{0, n, -1.0, -1, false});
+        stack.push_back(Frame{a0, b0, parent_sa0, -1, false});
         while (!stack.empty()) {
             Frame f = stack.back();
             stack.pop_back();
-            if (f.close) { node_skip[(size_t)f.node] = (int32_t)node_box.size(); continue; }
+            if (f.close) { out.skip[(size_t)f.node] = (int32_t)out.box.size(); continue; }
             const uint32_t m = f.b - f.a;
-            Box all = leaf_box[f.a];
-            for (uint32_t k = f.a + 1; k < f.b; k++) all = box_union(all, leaf_box[k]);
-            const double sa = surface_area(all);
-            const bool emit = m == 1 || f.parent_sa < 0.0 || sa < kPrune * f.parent_sa;
+            const Split sp = split(f.a, f.b, f.parent_sa, suffix);
             int32_t me = -1;
-            if (emit) {
-                me = (int32_t)node_box.size();
-                node_box.push_back(all);
-                node_leaf.push_back(m == 1 ? (int32_t)f.a : -1);
-                node_skip.push_back(0);
+            if (sp.emit) {
+                me = (int32_t)out.box.size();
+                out.box.push_back(sp.all);
+                out.leaf.push_back(m == 1 ? (int32_t)f.a : -1);
+                out.skip.push_back(0);
             }
-            if (m == 1) { node_skip[(size_t)me] = me + 1; continue; }
-            // best split by SAH over the fixed order: prefix boxes on the fly, suffix boxes precomputed
-            suffix.resize(m);
-            suffix[m - 1] = leaf_box[f.b - 1];
-            for (uint32_t k = m - 1; k-- > 0;) suffix[k] = box_union(leaf_box[f.a + k], suffix[k + 1]);
-            Box prefix = leaf_box[f.a];
-            double best = 0.0;
-            uint32_t best_k = 1;
-            for (uint32_t k = 1; k < m; k++) {           // left = [a, a+k), right = [a+k, b)
-                const double c = surface_area(prefix) * k + surface_area(suffix[k]) * (m - k);
-                if (k == 1 || c < best) { best = c; best_k = k; }
-                prefix = box_union(prefix, leaf_box[f.a + k]);
-            }
-            const double child_parent_sa = emit ? sa : f.parent_sa;
-            if (emit) stack.push_back(Frame{0, 0, 0.0, me, true});                         // runs after both subtrees
-            stack.push_back(Frame{f.a + best_k, f.b, child_parent_sa, -1, false});          // right: popped second
-            stack.push_back(Frame{f.a, f.a + best_k, child_parent_sa, -1, false});          // left: popped first
+            if (m == 1) { out.skip[(size_t)me] = me + 1; continue; }
+            const double child_parent_sa = sp.emit ? sp.sa : f.parent_sa;
+            if (sp.emit) stack.push_back(Frame{0, 0, 0.0, me, true});                         // runs after both subtrees
+            stack.push_back(Frame{f.a + sp.k, f.b, child_parent_sa, -1, false});              // right: popped second
+            stack.push_back(Frame{f.a, f.a + sp.k, child_parent_sa, -1, false});              // left: popped first
         }
+    }
+
+    // the same tree with the two halves of the large nodes built by different threads and concatenated (pre-order: own node, left, right)
+    void build_parallel(uint32_t a, uint32_t b, double parent_sa, Part& out, unsigned threads) const {
+        const uint32_t m = b - a;
+        if (threads <= 1 || m < 65536u) { build_serial(a, b, parent_sa, out); return; }
+        std::vector<Box> suffix;
+        const Split sp = split(a, b, parent_sa, suffix);
+        std::vector<Box>().swap(suffix);
+        int32_t me = -1;
+        if (sp.emit) {
+            me = (int32_t)out.box.size();
+            out.box.push_back(sp.all);
+            out.leaf.push_back(-1);
+            out.skip.push_back(0);
+        }
+        const double child_parent_sa = sp.emit ? sp.sa : parent_sa;
+        Part left, right;
+        // threads in proportion to the halves' sizes (SAH splits are uneven)
+        unsigned tl = (unsigned)(((uint64_t)threads * sp.k + m / 2) / m);
+        if (tl < 1) tl = 1;
+        if (tl >= threads) tl = threads - 1;
+        std::thread t([&] { build_parallel(a, a + sp.k, child_parent_sa, left, tl); });
+        build_parallel(a + sp.k, b, child_parent_sa, right, threads - tl);
+        t.join();
+        out.append(left);
+        out.append(right);
+        if (sp.emit) out.skip[(size_t)me] = (int32_t)out.box.size();
+    }
+
+    void build(unsigned threads) {
+        Part all;
+        build_parallel(0, (uint32_t)leaf_box.size(), -1.0, all, threads);
+        node_box.swap(all.box);
+        node_leaf.swap(all.leaf);
+        node_skip.swap(all.skip);
     }
 };
 
@@ -280,10 +381,7 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
     std::vector<uint32_t> order(ng);
     for (size_t g = 0; g < ng; g++) order[g] = (uint32_t)g;
     Builder b(prim_box);
-    b.node_box.reserve(2 * ng);
-    b.node_prim.reserve(2 * ng);
-    b.node_skip.reserve(2 * ng);
-    b.build(order.data(), ng, 1);
+    b.build(0, order.data(), ng, 1, host_threads());
     const uint32_t nn = (uint32_t)b.node_box.size();
 
     // culling tree over the reference tree's leaf sequence
@@ -295,7 +393,7 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
         if (b.node_prim[i] >= 0) { leaf_box.push_back(b.node_box[i]); leaf_geo.push_back(b.node_prim[i]); }
     }
     CullBuilder cb(leaf_box, opt.cull_prune > 0.0f ? (double)opt.cull_prune : 0.5);
-    cb.build();
+    cb.build(host_threads());
     const uint32_t nc = (uint32_t)cb.node_box.size();
     std::vector<int32_t> cull_prim_geo(nc);
     for (uint32_t i = 0; i < nc; i++) cull_prim_geo[i] = cb.node_leaf[i] >= 0 ? leaf_geo[(size_t)cb.node_leaf[i]] : -1;
@@ -437,7 +535,7 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
         f4[L.off_material + i] = F4{m.albedo.x, m.albedo.y, m.albedo.z, m.param};
         u32[L.off_material_kind + i] = m.kind;
     }
-    out.max_depth = b.max_depth;
+    out.max_depth = b.max_depth.load();
     return true;
 }
 
