@@ -172,6 +172,12 @@ def valu_roofline(key, avg_ms, rays_per_launch, warnings, single_gpu=True):
                 out["achieved"] = round(issue_rate * lanes / 1e3, 2)
                 out["frac"] = round(issue_frac * lanes / 64.0, 4)
                 out["lane_slot_frac"] = out["frac"]
+            if prof.get("GRBM_GUI_ACTIVE") and prof.get("trace_avg_ns"):
+                # the clock the chip really ran at while the profile was taken: GRBM_GUI_ACTIVE sums busy cycles over the 8 XCDs
+                eff = prof["GRBM_GUI_ACTIVE"] / 8.0 / prof["trace_avg_ns"]
+                out["effective_clock_ghz"] = round(eff, 3)
+                if out["frac"] is not None and eff > 0:
+                    out["frac_at_effective_clock"] = round(out["frac"] * CLOCK_GHZ / eff, 4)      # peak re-priced at that clock instead of the nominal 2.4 GHz
             if issue_frac > 1.0 or out["hbm_physical_frac"] > 1.0:
                 warnings.append(f"{key}: a fraction above 1: the stored PMC profile does not describe this run (other box clock, other build?)")
     elif prof is None:
@@ -179,6 +185,37 @@ def valu_roofline(key, avg_ms, rays_per_launch, warnings, single_gpu=True):
     elif stale:
         warnings.append(f"the PMC profile of {key} was taken from other kernel sources (pmc_stale): frac is null until tools/pmc_bench.sh is re-run")
     return out
+
+
+def isa_event_costs():
+    """profiles/isa_event_costs.json (tools/isa_event_costs.py): VALU lane-instructions one lane needs per event, counted in the gfx950 ISA
+    of the product's own device functions.  (table, stale): a table made from other kernel sources is not used."""
+    path = os.path.join(ROOT, "profiles", "isa_event_costs.json")
+    if not os.path.exists(path):
+        return None, False
+    with open(path) as f:
+        t = json.load(f)
+    return t, t.get("kernel_source_digest") != kernel_source_digest()
+
+
+UNIT_DISK_EXTRA_ITERATIONS = 4.0 / 3.141592653589793 - 1.0        # the rejection loop of vec3extend.rs:45-53 runs 4/pi times on average
+UNIT_DISK_LOOP_VALU = 14                                          # its body: two draws (rng_next 6 + mapping 2 each), the squared length and the compare
+
+
+def useful_lane_instructions(c, walk, n_quads, n_spheres, table):
+    """Lane-instructions the PATH'S ARITHMETIC needs for the events the counting pass counted: every event x what one lane
+    needs for it (isa_event_costs).  `c`: counters of a collect_stats=2 pass (box tests of the walk the production kernel performs);
+    `walk`: trt_launch_plan.walk of the production launch (which hand-written box-step loop runs)."""
+    ev, loops = table["events"], table["asm_loops"]
+    box = {1: loops["box_step_lds"], 2: loops["box_step_flat"], 3: loops["box_step_compact"]}.get(walk, ev["box_test"])
+    quads = n_quads >= n_spheres                                   # which primitive the shades' HitRecord is built for (bench scenes hold one kind)
+    shade = (c["shade_lambertian"] * ev["shade_lambertian_quad" if quads else "shade_lambertian_sphere"]
+             + c["shade_metal"] * ev["shade_metal_sphere"] + c["shade_dielectric"] * ev["shade_dielectric_sphere"]
+             + c["shade_light"] * ev["shade_light_quad"] + (c["rays"] - c["shades"]) * ev["shade_miss"])
+    parts = {"ray_setup": c["rays"] * ev["ray_setup"], "box_tests": c["node_tests"] * box,
+             "primitive_tests": c["quad_plane_tests"] * ev["quad_test"] + c["sphere_tests"] * ev["sphere_test"], "shades": shade,
+             "primary_rays": c["samples"] * (ev["primary_ray"] + UNIT_DISK_EXTRA_ITERATIONS * UNIT_DISK_LOOP_VALU)}
+    return sum(parts.values()), parts, box
 
 
 OTHER_SCENES = (   # BASELINE configs[2] and configs[4] at their own sizes: short untimed-by-the-driver runs reported beside the headline
@@ -372,7 +409,7 @@ def main():
     def step(i, stats=False, counters=ctr, target=acc):
         s0, s1, accumulate = step_range(i, S)
         renderer.render_device(cam, scene, target.data_ptr(), stream.cuda_stream, counters.data_ptr(),
-                               sample_begin=s0, sample_end=s1, accumulate=accumulate, collect_stats=1 if stats else 0,
+                               sample_begin=s0, sample_end=s1, accumulate=accumulate, collect_stats=int(stats),
                                **band)
 
     def barrier():
@@ -471,6 +508,37 @@ def main():
                 "note": "SURVEY 8(d): bytes the reference-order traversal would read per launch / launch time.  NOT a physical "
                         "fraction and not a roofline for this path: the scene is served from SGPRs / LDS / L2, so it exceeds 1 "
                         "(DESIGN.md section 8); the physical HBM traffic is `traffic`"}
+    # ---- useful-work fraction: what the path's arithmetic NEEDS against the chip's lane-slots (frac counts every issued lane-instruction) ----
+    table, table_stale = isa_event_costs()
+    if not args.no_roofline_pass and rows_local > 0 and avg_ms and n_launch and table is not None and not table_stale:
+        # one untimed step with the counting variant on the CULLING tree (collect_stats = 2): the box tests the production walk performs
+        uctr = torch.zeros(16, dtype=torch.int64, device=dev)
+        uscratch = torch.zeros_like(acc)
+        step(args.warmup, stats=2, counters=uctr, target=uscratch)
+        torch.cuda.synchronize()
+        names = ("samples", "rays", "node_tests", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades")
+        uc = dict(zip(names, [int(v) for v in uctr[:7].tolist()]))
+        uc.update(zip(("shade_lambertian", "shade_metal", "shade_dielectric", "shade_light"), [int(v) for v in uctr[12:16].tolist()]))
+        plan = renderer.launch_plan(cam, scene) if hasattr(renderer, "launch_plan") else None
+        walk = plan["walk"] if plan else 0
+        info = scene.info()
+        useful, parts, box_cost = useful_lane_instructions(uc, walk, info["num_quads"], info["num_spheres"], table)
+        per_ray = useful / max(uc["rays"], 1)
+        useful_rate = per_ray * rays_per_launch / (avg_ms * 1e-3) / 1e12             # T lane-instructions / s
+        roofline["useful_frac"] = round(useful_rate / (VALU_PEAK_GINST * 64.0 / 1e3), 4)
+        roofline["useful"] = {"lane_instructions_per_ray": round(per_ray, 1), "achieved_T_per_s": round(useful_rate, 2),
+                              "per_ray_by_event": {k: round(v / max(uc["rays"], 1), 1) for k, v in parts.items()},
+                              "box_tests_per_ray": round(uc["node_tests"] / max(uc["rays"], 1), 2), "valu_per_box_test": box_cost,
+                              "events_from": "one untimed step of the counting kernel on the culling tree (collect_stats = 2)",
+                              "costs_from": "profiles/isa_event_costs.json (tools/isa_event_costs.py: gfx950 ISA of the product's device functions)",
+                              "is": "lane-instructions the path's arithmetic needs (events x per-event VALU count) per second / peak lane-slots; "
+                                    "frac counts every lane-instruction ISSUED instead"}
+        if roofline.get("valu_wave_insts_per_ray") and roofline.get("mean_active_lanes"):
+            issued = roofline["valu_wave_insts_per_ray"] * roofline["mean_active_lanes"]
+            roofline["useful"]["issued_lane_instructions_per_ray"] = round(issued, 1)
+            roofline["useful"]["useful_over_issued"] = round(per_ray / issued, 3)
+    elif table is None or table_stale:
+        warnings.append("profiles/isa_event_costs.json is missing or was made from other kernel sources: no useful_frac (python tools/isa_event_costs.py)")
     roofline["warnings"] = warnings
     # per-rank summary on rank 0 (N > 1): launch time and rays of every rank
     per_rank = None

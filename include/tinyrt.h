@@ -250,7 +250,7 @@ int trt_band_copy_plan(uint32_t width, uint32_t height, uint32_t ndev, uint32_t 
 
 /* Same, on buffers already resident in HBM.  `d_accum`: device pointer, rows*width*3 f32.
  * `d_counters`: device pointer to 16 uint64 (zeroed by the caller; [0..6] = trt_stats' first seven
- * fields, [8..11] = wave_trips) or NULL.  `stream`: a hipStream_t (NULL = default stream).  Asynchronous: returns after
+ * fields, [8..11] = wave_trips, [12..15] with collect_stats: `shades` by material kind in enum trt_material_kind order) or NULL.  `stream`: a hipStream_t (NULL = default stream).  Asynchronous: returns after
  * enqueueing; the caller synchronises the stream.
  *
  * Concurrency (all render entry points): a scene is immutable once created and may be rendered by several host threads

@@ -125,3 +125,28 @@ def test_plain_multi_gpu_command_without_the_gpus_exits_nonzero_with_one_line():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and r.stdout == ""
     assert len(r.stderr.strip().splitlines()) == 1 and "needs 2 visible GPUs" in r.stderr
+
+
+def test_isa_event_costs_table_is_current_and_sane(bench):
+    """profiles/isa_event_costs.json (tools/isa_event_costs.py; refreshed by __graft_entry__.build()): made from the kernel sources in the
+    tree, the hand-written loops' counts are the documented ones, every event costs something, a light costs less than a scatter."""
+    table, stale = bench.isa_event_costs()
+    assert table is not None and not stale, "run python tools/isa_event_costs.py (or __graft_entry__.build())"
+    loops, ev = table["asm_loops"], table["events"]
+    assert (loops["box_step_flat"], loops["box_step_lds"], loops["box_step_compact"], loops["slab_test_alone"]) == (25, 29, 37, 23)    # DESIGN 5.2-5.4
+    assert all(v > 0 for v in ev.values())
+    assert ev["shade_light_quad"] < ev["shade_dielectric_sphere"] < ev["shade_metal_sphere"] <= ev["shade_lambertian_sphere"]
+    assert ev["shade_miss"] < 20 and 20 <= ev["box_test"] <= 40 and 100 < ev["primary_ray"] < 400
+
+
+def test_useful_lane_instructions_adds_up(bench):
+    table, _ = bench.isa_event_costs()
+    ev, loops = table["events"], table["asm_loops"]
+    c = dict(samples=10, rays=70, node_tests=1260, sphere_tests=0, quad_plane_tests=76, quad_inside_tests=70, shades=65, shade_lambertian=56,
+             shade_metal=0, shade_dielectric=0, shade_light=9)
+    total, parts, box = bench.useful_lane_instructions(c, 2, 18, 0, table)                  # walk 2 = the lock-step leaf list
+    assert box == loops["box_step_flat"] and parts["box_tests"] == 1260 * 25
+    assert parts["shades"] == 56 * ev["shade_lambertian_quad"] + 9 * ev["shade_light_quad"] + 5 * ev["shade_miss"]
+    assert abs(total - sum(parts.values())) < 1e-6 and parts["ray_setup"] == 70 * ev["ray_setup"]
+    _, parts_s, box_s = bench.useful_lane_instructions(dict(c, sphere_tests=100, quad_plane_tests=0), 3, 0, 1000, table)
+    assert box_s == loops["box_step_compact"] and parts_s["primitive_tests"] == 100 * ev["sphere_test"]

@@ -294,6 +294,13 @@ class Renderer:
         self.last_stats = st.as_dict()
         return Image(accum)
 
+    def launch_plan(self, camera, scene, **over):
+        """trt_streamed_launch_plan: how the streamed backend launches this render (host arithmetic only), as a dict."""
+        plan = _lib.LaunchPlan()
+        p = self.params(**over)
+        check(lib.trt_streamed_launch_plan(scene._h, C.byref(camera.pod), C.byref(p), C.byref(plan)))
+        return {n: getattr(plan, n) for n, _ in plan._fields_}
+
     def render_device(self, camera, scene, d_accum_ptr, stream_ptr=0, d_counters_ptr=0, **over):
         """Enqueue one pass on buffers already in HBM (device pointers as integers); asynchronous."""
         p = self.params(**over)

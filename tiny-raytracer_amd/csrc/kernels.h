@@ -67,8 +67,10 @@ inline uint32_t rng_seed_key(uint32_t seed) {
 // counters[0..6] = samples, rays, node_tests, sphere_tests, quad_plane_tests, quad_inside_tests, shades
 // counters[8..11] (collect_stats only) = wave-level loop trips: bounce rounds, box-test steps, leaf phases, ray generations
 // counters[7] (collect_stats, lock-step walk only) = leaves put aside, summed over lanes (a diagnostic read through trt_render_device's counters)
+// counters[12..15] (collect_stats only) = `shades` by material kind (trt_material_kind order: Lambertian, Metal, Dielectric, Light); they sum
+//                  to counters[6] (bench.py useful_frac; read through trt_render_device's counters; the phase-clock build keeps its clock there)
 enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_PEND = 7,
-       CTR_W_ROUNDS = 8, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_COUNT = 16 };
+       CTR_W_ROUNDS = 8, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_SHADE_KIND = 12, CTR_COUNT = 16 };
 
 // scene.h kLdsSceneMaxBytes: hot blobs up to that size are copied whole into LDS; larger scenes keep only the culling
 // tree's top levels there (TRT_TOP_NODES) or nothing.

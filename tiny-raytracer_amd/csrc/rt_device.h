@@ -17,6 +17,14 @@
 #include <stdint.h>
 
 #define TRT_DEV __device__ __forceinline__
+// The plain-IEEE fallbacks of the short division / sqrt sequences below run for operands outside [2^-40, 2^40] only - never in a bench
+// scene.  They are inlined like everything else; tools/micro/event_costs.hip alone defines TRT_EVENT_COSTS to keep them OUT of line, so
+// that its static instruction counts (profiles/isa_event_costs.json: what one lane needs per event) are those of the path really taken.
+#ifdef TRT_EVENT_COSTS
+#define TRT_COLD __device__ __noinline__
+#else
+#define TRT_COLD __device__ __forceinline__
+#endif
 
 namespace trt {
 
@@ -66,6 +74,7 @@ TRT_DEV float sqrt_in_range(float x) {                                          
 // Vec3::normalized (vec3.rs:45-47): a / sqrt(a.a).  Components in [2^-39, 2^39] put the squared length into [2^-78, 2^80) and the
 // length into [2^-39, 2^40): both short forms apply; anything else (a zero component - the 0/0 of vec3extend.rs:32-34 when u3 = 0
 // included -, subnormals, huge values, infinities) takes the plain sqrtf and the three plain divisions.
+TRT_COLD V3 normalized_plain(V3 a, float sq) { return a / __builtin_sqrtf(sq); }
 TRT_DEV V3 normalized(V3 a) {
     const float lo = 1.8189894035458565e-12f, hi = 549755813888.0f;                     // 2^-39, 2^39
     const float ax = __builtin_fabsf(a.x), ay = __builtin_fabsf(a.y), az = __builtin_fabsf(a.z);
@@ -78,7 +87,7 @@ TRT_DEV V3 normalized(V3 a) {
         const float r1 = __builtin_fmaf(e, r0, r0);
         return v3(div_by_refined_rcp(a.x, b, r1), div_by_refined_rcp(a.y, b, r1), div_by_refined_rcp(a.z, b, r1));
     }
-    return a / __builtin_sqrtf(sq);
+    return normalized_plain(a, sq);
 }
 TRT_DEV V3 cross(V3 a, V3 b) {                                                       // vec3.rs:53-59
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
@@ -135,13 +144,14 @@ TRT_DEV float dm_asin_poly(float z) {
 // x < -0.5: pi - 2 asin(sqrt((1+x)/2))): every lane performs exactly the operations of its own range (1 + x for a
 // negative x IS 1 - |x|), selected instead of branched to - the lanes of a wave fall into all three ranges
 // (x = 1 - 2u), so branches made the wave issue all three bodies.
+TRT_COLD float sqrt_plain(float z) { return __builtin_sqrtf(z); }
 TRT_DEV float dm_acos(float x) {
     const float PI_F = 3.14159265358979323846f, PIO2_F = 1.57079632679489661923f;
     const float ax = __builtin_fabsf(x);
     const bool big = ax > 0.5f;
     const float z = big ? 0.5f * (1.0f - ax) : x * x;
     // z <= 0.25; it is 0 for x = +-1 and tiny next to it: the short sqrt applies from 2^-80 up
-    const float w = big ? (__builtin_expect(z >= 8.271806125530277e-25f, 1) ? sqrt_in_range(z) : __builtin_sqrtf(z)) : x;
+    const float w = big ? (__builtin_expect(z >= 8.271806125530277e-25f, 1) ? sqrt_in_range(z) : sqrt_plain(z)) : x;
     const float r = __builtin_fmaf(dm_asin_poly(z) * z, w, w);
     const float two_r = r + r;
     return big ? (x > 0.0f ? two_r : PI_F - two_r) : PIO2_F - r;

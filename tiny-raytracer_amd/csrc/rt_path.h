@@ -79,6 +79,7 @@ template <bool STATS>
 struct Counters {
     uint32_t node = 0, sphere = 0, quad_plane = 0, quad_inside = 0, shade = 0;
     uint32_t pend = 0;                                             // leaves put aside by the lock-step walk (diagnostic: tools/leaf_phase_budget.py)
+    uint32_t shade_lambertian = 0, shade_metal = 0, shade_dielectric = 0, shade_light = 0;     // `shade` by material kind (bench.py useful_frac)
     uint32_t w_rounds = 0, w_steps = 0, w_leaf = 0, w_gen = 0;     // wave-level trips, counted by the first active lane
 #ifdef TRT_PHASE_CLOCK
     PhaseClock clk;
@@ -945,6 +946,10 @@ TRT_DEV bool shade_hit(const SceneAcc<MODE>& sc, Path& p, uint32_t prim, float t
     const float4 m = sc.material(mat);
     const uint32_t kind = sc.material_kind(mat);
     const V3 albedo = v3(m.x, m.y, m.z);
+    if constexpr (STATS) {
+        ctr.shade_lambertian += kind == TRT_LAMBERTIAN; ctr.shade_metal += kind == TRT_METAL;
+        ctr.shade_dielectric += kind == TRT_DIELECTRIC; ctr.shade_light += kind == TRT_LIGHT;
+    }
     // cpu.rs:49-50: emitted() is the light's colour, None -> 0 for everything else (material/mod.rs:8-10)
     if constexpr (LAZY) {
         p.color = v3(0.0f, 0.0f, 0.0f);                                // what the sum is after any hit that is not a light
@@ -1059,10 +1064,17 @@ TRT_DEV void flush_counters(unsigned long long* counters, uint32_t samples, uint
     if (lane0) { for (int k = 0; k < 4; k++) atomicAdd(&counters[12 + k], (unsigned long long)ctr.clk.t[k]); }
 #endif
     if constexpr (STATS) {
-        uint32_t v[10] = {ctr.node, ctr.sphere, ctr.quad_plane, ctr.quad_inside, ctr.shade, ctr.w_rounds, ctr.w_steps, ctr.w_leaf, ctr.w_gen, ctr.pend};
-        const int slot[10] = {CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_W_ROUNDS, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_PEND};
+#ifdef TRT_PHASE_CLOCK
+        constexpr int kN = 10;                                     // counters[12..15] carry the phase clock in that build
+#else
+        constexpr int kN = 14;
+#endif
+        uint32_t v[14] = {ctr.node, ctr.sphere, ctr.quad_plane, ctr.quad_inside, ctr.shade, ctr.w_rounds, ctr.w_steps, ctr.w_leaf, ctr.w_gen, ctr.pend,
+                          ctr.shade_lambertian, ctr.shade_metal, ctr.shade_dielectric, ctr.shade_light};
+        const int slot[14] = {CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_W_ROUNDS, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_PEND,
+                              CTR_SHADE_KIND + 0, CTR_SHADE_KIND + 1, CTR_SHADE_KIND + 2, CTR_SHADE_KIND + 3};
 #pragma unroll
-        for (int k = 0; k < 10; k++) {
+        for (int k = 0; k < kN; k++) {
             uint32_t t = wave_sum(v[k]);
             if (lane0 && t) atomicAdd(&counters[slot[k]], (unsigned long long)t);
         }
