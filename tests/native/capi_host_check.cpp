@@ -383,6 +383,22 @@ static void failure_injection() {
         unsetenv("HIPSTUB_HBM_BYTES");
         CHECK(rc == TRT_OK && f == expected(128, 100, 11, 0, 8), "render with HBM short: rc %d %s", rc, trt_last_error());
         CHECK(launch_stub_short_launches() > before, "the render was not granted a smaller workspace");
+        // the pressure LASTS: the next renders start from the size that was granted - no hipFree + failing full-size hipMalloc +
+        // hipMalloc of the shorter workspace per render - and still render the same frame
+        setenv("HIPSTUB_HBM_BYTES", cap, 1);
+        const long mallocs_before = hipstub_malloc_calls();
+        for (int k = 0; k < 3; k++) {
+            const int rck = trt_render(s, &cam, &p, f.data(), nullptr);
+            CHECK(rck == TRT_OK && f == expected(128, 100, 11, 0, 8), "render %d under lasting pressure: rc %d %s", k, rck, trt_last_error());
+        }
+        CHECK(hipstub_malloc_calls() == mallocs_before, "%ld device allocations in three renders under lasting pressure (expected none: the granted workspace is reused)",
+              hipstub_malloc_calls() - mallocs_before);
+        // ... and once the memory is back (hipMemGetInfo), the next render takes its full-size launch again
+        unsetenv("HIPSTUB_HBM_BYTES");
+        const long short_before = launch_stub_short_launches();
+        const int rcf = trt_render(s, &cam, &p, f.data(), nullptr);
+        CHECK(rcf == TRT_OK && f == expected(128, 100, 11, 0, 8) && launch_stub_short_launches() == short_before, "render after the pressure: rc %d, %ld short launches",
+              rcf, launch_stub_short_launches() - short_before);
         trt_scene_destroy(s);
     }
     printf("ok failure injection (%d failed calls recovered from)\n", failed_calls);

@@ -32,6 +32,7 @@ hipError_t hipGetDevice(int* d);
 hipError_t hipSetDevice(int d);
 hipError_t hipMalloc(void** p, size_t bytes);
 hipError_t hipFree(void* p);
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s);
 hipError_t hipMemcpy2DAsync(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t height, hipMemcpyKind kind, hipStream_t s);
@@ -59,6 +60,7 @@ long hipstub_live_allocations(void);
 long hipstub_live_streams(void);
 long hipstub_live_events(void);
 size_t hipstub_live_bytes(void);
+long hipstub_malloc_calls(void);                                      // hipMalloc calls so far (failed ones included)
 size_t hipstub_peak_bytes(void);
 void hipstub_reset_peak(void);
 // Operation log (ordering tests): while on, every copy / memset the stub EXECUTES - and whatever a launcher stub reports through

@@ -152,7 +152,10 @@ hipError_t hipGetDeviceCount(int* n) { *n = device_count(); return hipSuccess; }
 hipError_t hipGetDevice(int* d) { *d = t_device; return hipSuccess; }
 hipError_t hipSetDevice(int d) { if (d < 0 || d >= device_count()) return ret(hipErrorInvalidDevice); t_device = d; return hipSuccess; }
 
+static std::atomic<long> g_malloc_calls{0};
+long hipstub_malloc_calls(void) { return g_malloc_calls.load(); }
 hipError_t hipMalloc(void** p, size_t bytes) {
+    g_malloc_calls++;
     if (inject("hipMalloc")) { *p = nullptr; return ret(hipErrorOutOfMemory); }
     const char* cap = getenv("HIPSTUB_HBM_BYTES");
     std::lock_guard<std::mutex> lock(g_mu);
@@ -165,6 +168,15 @@ hipError_t hipMalloc(void** p, size_t bytes) {
     g_live_bytes += bytes;
     if (g_live_bytes > g_peak_bytes) g_peak_bytes = g_live_bytes;
     *p = q;
+    return hipSuccess;
+}
+hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {
+    if (inject("hipMemGetInfo")) return ret(hipErrorUnknown);
+    const char* cap = getenv("HIPSTUB_HBM_BYTES");
+    std::lock_guard<std::mutex> lock(g_mu);
+    const size_t total = cap ? (size_t)strtoull(cap, nullptr, 10) : ((size_t)288 << 30);
+    *total_b = total;
+    *free_b = total > g_live_bytes ? total - g_live_bytes : 0;
     return hipSuccess;
 }
 hipError_t hipFree(void* p) {

@@ -135,9 +135,11 @@ def test_at_size_schedules_agree(trt, case):
 
 
 FULL_SPP = {
-    # BASELINE configs[2] and configs[4] at their FULL sample counts, once each: (scene, W, H, spp, split) - `split` lies inside
+    # BASELINE configs[1], configs[2] and configs[4] at their FULL sample counts, once each: (scene, W, H, spp, split) - `split` lies inside
     # the first launch's sample range, so the two progressive passes cut the frame's launches (512 spp = 2 x 256 at 1080p, 256 spp = 2 x 128
     # at 2160p: streamed.hip streamed_chunk_spp) at other places than the one-pass render does
+    # configs[1] too (the one BASELINE sample count that had never been rendered in full under test): 1024 spp = 4 x 256 at 800x800
+    "cfg2_cornell_800_1024spp": (lambda trt: trt.scenes.cornell(800, 800), 1024, 300),
     "cfg3_random_spheres_1080p_512spp": (lambda trt: trt.scenes.random_spheres(1920, 1080), 512, 300),
     "cfg5_sphere_grid100k_2160p_256spp": (lambda trt: trt.scenes.sphere_grid(100000, 3840, 2160), 256, 100),
 }

@@ -115,6 +115,7 @@ struct DeviceCache {
     bool blob_busy = false;                       // a thread is uploading it
     std::vector<Workspace*> ws;
     std::vector<RenderCtx*> ctx;
+    uint32_t short_samples = 0;                   // != 0: the last streamed render of a full-size launch was granted scratch for this many samples only
 };
 
 struct trt_scene {
@@ -521,10 +522,42 @@ int enqueue_render(trt_scene* s, const trt_camera* cam, const trt_render_params*
             uint32_t samples = ra.sample_end - ra.sample_begin;
             const uint32_t full = streamed_chunk_spp(cam->width, rows, tn.radiance_gb);
             if (samples > full) samples = full;
+            const uint32_t wanted = samples;
+            // Lasting pressure: while the device still cannot hold the full request, start where the last render ended up instead
+            // of freeing the cached shorter workspace, failing the full-size hipMalloc and allocating the shorter one again on every render.
+            // hipMemGetInfo says when the pressure is gone: free memory + this scene's own idle scratch (a regrow frees it first) covers the request.
+            {
+                uint32_t short_samples = 0;
+                size_t idle = 0;
+                {
+                    std::lock_guard<std::mutex> lock(s->mu);
+                    DeviceCache& dc = s->dev[dev];
+                    short_samples = dc.short_samples;
+                    for (Workspace* w : dc.ws) if (!w->busy) idle += w->bytes;
+                }
+                if (short_samples != 0u && short_samples < samples) {
+                    size_t free_b = 0, total_b = 0;
+                    const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+                    (void)hipGetLastError();
+                    if (!known || free_b + idle < streamed_workspace_bytes(cam->width, rows, samples, tn.radiance_gb)) samples = short_samples;
+                }
+            }
+            bool trimmed = false;
             for (;;) {
                 rc = workspace_acquire(s, dev, streamed_workspace_bytes(cam->width, rows, samples, tn.radiance_gb), stream, &ws);
-                if (rc != TRT_ERR_OOM || samples <= 1u) break;
+                if (rc != TRT_ERR_OOM) break;
+                if (!trimmed) {                      // first give back what this scene itself keeps idle on the device (frames of idle contexts, other workspaces), then ask again
+                    trimmed = true;
+                    std::unique_lock<std::mutex> lock(s->mu);
+                    trim_locked(s, lock, s->dev[dev], 0);
+                    continue;
+                }
+                if (samples <= 1u) break;
                 samples = (samples + 1u) / 2u;
+            }
+            {
+                std::lock_guard<std::mutex> lock(s->mu);
+                s->dev[dev].short_samples = (rc == TRT_OK && samples < wanted) ? samples : 0u;
             }
         }
         if (rc != TRT_OK) return rc;
