@@ -181,7 +181,6 @@ hipError_t launch_megakernel(const SceneDev& sc, const CameraDev& cam, const Ren
             if (w == 7) return stats ? go(megakernel<MODE_LDS, true, 7>) : go(megakernel<MODE_LDS, false, 7>);
             if (w == 6) return stats ? go(megakernel<MODE_LDS, true, 6>) : go(megakernel<MODE_LDS, false, 6>);
             return stats ? go(megakernel<MODE_LDS, true, 5>) : go(megakernel<MODE_LDS, false, 5>);
-        case MODE_HYBRID: return stats ? go(megakernel<MODE_HYBRID, true>) : go(megakernel<MODE_HYBRID, false>);
         default:
             if (tn.mega_global_waves8) return stats ? go(megakernel<MODE_GLOBAL, true, 8>) : go(megakernel<MODE_GLOBAL, false, 8>);
             return stats ? go(megakernel<MODE_GLOBAL, true>) : go(megakernel<MODE_GLOBAL, false>);
@@ -196,7 +195,6 @@ hipError_t launch_sample_batch(const SceneDev& sc, const trt_sample_point* d_in,
     auto go = [&](auto kernel) { return launch(kernel, grid, block, lds_bytes, stream, sc, d_in, n, d_out, ra, d_counters); };
     switch (scene_mode(sc.L)) {
         case MODE_LDS: return stats ? go(sample_batch_kernel<MODE_LDS, true>) : go(sample_batch_kernel<MODE_LDS, false>);
-        case MODE_HYBRID: return stats ? go(sample_batch_kernel<MODE_HYBRID, true>) : go(sample_batch_kernel<MODE_HYBRID, false>);
         default: return stats ? go(sample_batch_kernel<MODE_GLOBAL, true>) : go(sample_batch_kernel<MODE_GLOBAL, false>);
     }
 }

@@ -305,7 +305,6 @@ hipError_t launch_wavefront(const SceneDev& sc, const CameraDev& cam, const Rend
     };
     switch (scene_mode(sc.L)) {
         case MODE_LDS: return stats ? go(wavefront_kernel<MODE_LDS, true>) : go(wavefront_kernel<MODE_LDS, false>);
-        case MODE_HYBRID: return stats ? go(wavefront_kernel<MODE_HYBRID, true>) : go(wavefront_kernel<MODE_HYBRID, false>);
         default: {
             int w = 6;                              // 80 VGPRs, 12 B of scratch: +2 % over the 87-VGPR / 5-wave allocation; 7, 8: slower
             if (tn.wf_waves_per_simd) w = (int)tn.wf_waves_per_simd;
