@@ -128,7 +128,8 @@ pub struct trt_tuning {
     pub wf_waves_per_simd: u32,
     pub wf_serve_min: u32,
     pub no_top_cache: u32,
-    pub reserved: [u32; 6],
+    pub top_burst: u32,
+    pub reserved: [u32; 5],
 }
 
 #[repr(C)]

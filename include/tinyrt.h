@@ -35,7 +35,7 @@ extern "C" {
                              * 3 (round 4): tuning moved out of the process environment: trt_tuning (trt_render_params.tuning),
                              *              trt_scene_options + trt_scene_create_ex; trt_stats.gather_per_band
                              * 4 (round 5): + trt_world_add_spheres, trt_scene_get_hybrid_nodes; trt_scene_options.top_nodes now sizes the
-                             *              top-in-LDS split of the 16-byte culling tree; trt_tuning.no_top_cache (was reserved[0]);
+                             *              top-in-LDS split of the 16-byte culling tree; trt_tuning.no_top_cache, .top_burst (were reserved[0..1]);
                              *              d_counters[12..15] = shades by material kind.  No struct changed size or moved a field. */
 
 enum trt_status {
@@ -187,7 +187,8 @@ typedef struct {
     uint32_t wf_waves_per_simd;       /* wavefront backend: 0 = default                                     TRT_WF_MINW */
     uint32_t wf_serve_min;            /* wavefront backend: lanes that must wait before a refill; 0 = default (12)   TRT_WF_SERVE_MIN */
     uint32_t no_top_cache;            /* 1: walk a scene that carries the top-in-LDS split (trt_scene_options.top_nodes) with the plain 16-byte-node walk (0)   TRT_NO_TOP_CACHE */
-    uint32_t reserved[6];             /* zero */
+    uint32_t top_burst;               /* top-in-LDS walk: box steps a lane may take out of LDS per round, while the wave's global loads are in flight; 0 = default (4)   TRT_TOP_BURST */
+    uint32_t reserved[5];             /* zero */
 } trt_tuning;
 void trt_tuning_default(trt_tuning *out);
 

@@ -559,7 +559,7 @@ def test_tuning_and_scene_option_defaults(trt):
     t = trt.tuning().as_dict()
     assert (t["stream_batch_spp"], t["radiance_gb"], t["lds_leaf_stack"], t["ray_pool"], t["stragglers"], t["lds_stragglers"]) == (8, 16, 1, 1, 8, 8)
     assert all(t[k] == 0 for k in ("stream_waves_per_simd", "stream_big_threads", "leaf_slots", "dual_walk", "runtime_walk", "xcd_remap",
-                                   "mega_waves_per_simd", "mega_threads", "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min", "no_top_cache"))
+                                   "mega_waves_per_simd", "mega_threads", "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min", "no_top_cache", "top_burst"))
     o = trt.scene_options()
     assert abs(o.cull_prune - 0.5) < 1e-7 and (o.flat_walk, o.compact_nodes, o.top_nodes, o.scratch_cap_bytes) == (-1, -1, 0, 32 << 30)
     with pytest.raises(TypeError):

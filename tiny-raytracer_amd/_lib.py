@@ -76,8 +76,8 @@ class Tuning(C.Structure):
     """tinyrt.h trt_tuning: scheduling / placement knobs of a render; every value renders the same frame."""
     FIELDS = ("stream_waves_per_simd", "stream_big_threads", "stream_batch_spp", "radiance_gb", "leaf_slots", "lds_leaf_stack", "ray_pool",
               "stragglers", "lds_stragglers", "dual_walk", "runtime_walk", "xcd_remap", "mega_waves_per_simd", "mega_threads",
-              "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min", "no_top_cache")
-    _fields_ = [(n, C.c_uint32) for n in FIELDS] + [("reserved", C.c_uint32 * 6)]
+              "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min", "no_top_cache", "top_burst")
+    _fields_ = [(n, C.c_uint32) for n in FIELDS] + [("reserved", C.c_uint32 * 5)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n in self.FIELDS}

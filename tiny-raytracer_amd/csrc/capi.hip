@@ -161,7 +161,7 @@ const Defaults& defaults() {
         u32("TRT_STREAM_MINW", t.stream_waves_per_simd); u32("TRT_BIG_THREADS", t.stream_big_threads); u32("TRT_STREAM_BATCH_SPP", t.stream_batch_spp);
         u32("TRT_RADIANCE_GB", t.radiance_gb); u32("TRT_LEAF_SLOTS", t.leaf_slots); u32("TRT_LDS_LEAF_STACK", t.lds_leaf_stack);
         u32("TRT_RAY_POOL", t.ray_pool); u32("TRT_STRAGGLERS", t.stragglers); u32("TRT_LDS_STRAGGLERS", t.lds_stragglers);
-        u32("TRT_DUAL_WALK", t.dual_walk); u32("TRT_NO_TOP_CACHE", t.no_top_cache); u32("TRT_RUNTIME_WALK", t.runtime_walk); u32("TRT_XCD_REMAP", t.xcd_remap);
+        u32("TRT_DUAL_WALK", t.dual_walk); u32("TRT_NO_TOP_CACHE", t.no_top_cache); u32("TRT_TOP_BURST", t.top_burst); u32("TRT_RUNTIME_WALK", t.runtime_walk); u32("TRT_XCD_REMAP", t.xcd_remap);
         u32("TRT_MINW", t.mega_waves_per_simd); u32("TRT_MEGA_THREADS", t.mega_threads); u32("TRT_MINW8", t.mega_global_waves8);
         u32("TRT_WF_MINW", t.wf_waves_per_simd); u32("TRT_WF_SERVE_MIN", t.wf_serve_min);
         trt_scene_options& o = x.scene;
@@ -485,6 +485,7 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     ra.lds_leaf_stack = tn.lds_leaf_stack;                 // 0 off, 1 where it costs no occupancy, 2 always
     ra.xcd_aware = tn.xcd_remap ? 1u : 0u;                 // off: contiguous image regions per XCD measured 2x slower (load imbalance)
     ra.stragglers = tn.stragglers;                         // profiles/r03_stragglers_sweep.txt
+    ra.top_burst = tn.top_burst;                           // (launch_streamed fills in the default)
     ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;
 }

@@ -33,6 +33,7 @@ struct RenderArgs {
     uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
     uint32_t stragglers;         // streamed walks of scenes in global memory: a round's walk phase ends once at most this many lanes of the wave still walk
                                  // (they carry their walk into the next round); 0 = every walk runs to its end (rt_path.h walk_compact)
+    uint32_t top_burst;          // top-in-LDS walk: steps a lane may take out of LDS while the wave's global node loads are in flight (rt_path.h box_loop_hybrid)
 };
 
 // The built-in scheduling defaults (tinyrt.h trt_tuning; each a measured optimum, DESIGN.md "Tuning").  They live in THIS header -
@@ -49,6 +50,7 @@ inline trt_tuning tuning_builtin() {
     t.ray_pool = 1;
     t.stragglers = 8;                 // profiles/r03_stragglers_sweep.txt
     t.lds_stragglers = 8;
+    t.top_burst = 0;                  // 4
     t.no_top_cache = 0;               // a scene compiled with a top part (trt_scene_options.top_nodes) is walked with it in LDS
     t.dual_walk = 0;                  // two paths per lane: +2 % at 6 waves per SIMD, -7 % at 8 (profiles/r04_dual_walk_sweep.txt): not the default
     t.runtime_walk = 0;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                 Trav tr = trav_begin(sc, p.ray, false);                              // every lane: a new walk, or the frame of a parked one
                 if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
+                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered, ra.top_burst);
                 if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
                         radiance_store(colors, out_idx, p.color);
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                 Trav tr = trav_begin(sc, p.ray, false);                              // see stream_sample_kernel
                 if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
+                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered, ra.top_burst);
                 if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
                         radiance_store(colors, out_idx, p.color);
@@ -738,6 +738,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         if (walk_of_plan == WALK_LDS_STACK) {                                   // the LDS tree walk's own straggler threshold
             ra.stragglers = tn.lds_stragglers;
         }
+        ra.top_burst = tn.top_burst ? (tn.top_burst > 64u ? 64u : tn.top_burst) : 4u;      // top-in-LDS walk: steps out of LDS per global round
         if (!pl.lds_stack || pl.slots < 2u) ra.stragglers = 0u;                 // a parked walk occupies two slots of the lane's LDS leaf stack (rt_path.h trav_park)
         ra.sample_begin = s0;
         ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;

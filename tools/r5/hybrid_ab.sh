@@ -9,8 +9,9 @@ G="--scene sphere_grid --width 3840 --height 2160 --spp-per-step 16 --steps 3 --
 F="--scene sphere_field --width 3840 --height 2160 --spp-per-step 4 --steps 3 --warmup 1 --cpu-seconds 0 --no-roofline-pass"
 run() { timeout -k 10 400 python3 bench.py "$@" 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f Mray/s %8.2f ms  %s' % (d['value'], d['roofline']['avg_launch_ms'], d['roofline']['kernel']))"; }
 {
-for top in 0 64 160 320 480 640 960 1280; do echo "100 k spheres, top_nodes=$top: $(TRT_TOP_NODES=$top run $G)"; done
-echo "100 k spheres, top_nodes=0 again: $(TRT_TOP_NODES=0 run $G)"
-for top in 320 1280; do for st in 4 16; do echo "100 k spheres, top_nodes=$top stragglers=$st: $(TRT_TOP_NODES=$top run $G --tuning stragglers=$st)"; done; done
-for n in 1000000 4000000; do for top in 0 320 640 1280; do echo "sphere_field $n, top_nodes=$top: $(TRT_TOP_NODES=$top run $F --spheres $n)"; done; done
-} 2>&1 | tee $out/sweep.txt
+echo "100 k spheres, plain walk (top_nodes=0): $(TRT_TOP_NODES=0 run $G)"
+for top in 64 320 640 1280; do for burst in 1 2 4 8; do echo "100 k spheres, top_nodes=$top burst=$burst: $(TRT_TOP_NODES=$top TRT_TOP_BURST=$burst run $G)"; done; done
+echo "100 k spheres, plain walk again: $(TRT_TOP_NODES=0 run $G)"
+for st in 4 16; do echo "100 k spheres, top_nodes=640 burst=4 stragglers=$st: $(TRT_TOP_NODES=640 run $G --tuning stragglers=$st)"; done
+for n in 1000000 4000000; do for top in 0 320 1280; do echo "sphere_field $n, top_nodes=$top: $(TRT_TOP_NODES=$top run $F --spheres $n)"; done; done
+} 2>&1 | tee $out/sweep2.txt
