@@ -172,6 +172,21 @@ def valu_roofline(key, avg_ms, rays_per_launch, warnings, single_gpu=True):
                 out["achieved"] = round(issue_rate * lanes / 1e3, 2)
                 out["frac"] = round(issue_frac * lanes / 64.0, 4)
                 out["lane_slot_frac"] = out["frac"]
+            # HBM side of the same launch (north_star: "rocprof-reported achieved HBM GB/s against the chip's peak").  FETCH_SIZE / WRITE_SIZE count the
+            # L2's fabric-side requests in KiB: what misses L2 - Infinity Cache hits INCLUDED (the guide: no counter separates them), so this
+            # bounds the HBM traffic from above; FETCH_SIZE tallies 128-byte requests at 64 bytes on gfx950, hence x 2.
+            if prof.get("FETCH_SIZE") is not None:
+                t_s = avg_ms * 1e-3
+                rd = 2.0 * prof["FETCH_SIZE"] * 1024.0 * scale
+                wr = prof.get("WRITE_SIZE", 0.0) * 1024.0 * scale
+                hbm_block = {"read_GBps": round(rd / t_s / 1e9, 1), "write_GBps": round(wr / t_s / 1e9, 1),
+                             "read_frac_of_peak": round(rd / t_s / 1e9 / HBM_PEAK_GBPS, 4), "read_bytes_per_ray": round(rd / max(rays_per_launch, 1), 1),
+                             "peak_GBps": HBM_PEAK_GBPS, "counts": "L2 misses (fabric requests): Infinity Cache hits included, no counter separates them"}
+                if prof.get("TCC_HIT_sum") is not None and prof.get("TCC_MISS_sum") is not None:
+                    hbm_block["l2_hit_rate"] = round(prof["TCC_HIT_sum"] / max(prof["TCC_HIT_sum"] + prof["TCC_MISS_sum"], 1.0), 4)
+                if prof.get("SQ_WAIT_ANY") and prof.get("SQ_WAVE_CYCLES"):
+                    hbm_block["wave_cycles_waiting"] = round(prof["SQ_WAIT_ANY"] / prof["SQ_WAVE_CYCLES"], 3)
+                out["hbm"] = hbm_block
             if prof.get("GRBM_GUI_ACTIVE") and prof.get("trace_avg_ns"):
                 # the clock the chip really ran at while the profile was taken: GRBM_GUI_ACTIVE sums busy cycles over the 8 XCDs
                 eff = prof["GRBM_GUI_ACTIVE"] / 8.0 / prof["trace_avg_ns"]
@@ -218,18 +233,25 @@ def useful_lane_instructions(c, walk, n_quads, n_spheres, table):
     return sum(parts.values()), parts, box
 
 
-OTHER_SCENES = (   # BASELINE configs[2] and configs[4] at their own sizes: short untimed-by-the-driver runs reported beside the headline
-    ("random_spheres", 1920, 1080, 256, 3, 1),
-    ("sphere_grid", 3840, 2160, 16, 3, 2),
+OTHER_SCENES = (   # BASELINE configs[2] and configs[4] at their own sizes: short untimed-by-the-driver runs reported beside the headline,
+    # and (round 5) the deep-BVH scene at a size BEYOND the 256 MiB Infinity Cache: 4 M spheres, 809 MB packed, ~300 MB of it
+    # touched per frame - the one scene whose walk reads HBM, where north_star's HBM fraction is a number
+    # (scene, spheres, width, height, spp per step, steps, warm-up)
+    ("random_spheres", 0, 1920, 1080, 256, 3, 1),
+    ("sphere_grid", 0, 3840, 2160, 16, 3, 2),
+    ("sphere_field", 4_000_000, 3840, 2160, 4, 3, 1),
 )
 
 
-def short_run(trt, torch, dev, scene_name, W, H, S, steps, warmup, depth, backend_name, backend):
-    """A few steps of another BASELINE scene at its own size on this GPU, after the timed region of the headline workload: value,
-    ms per step, the dominant kernel's launch time (HIP events on its launch stream) and its lane-slot fraction."""
-    desc = {"random_spheres": trt.scenes.random_spheres, "sphere_grid": lambda w, h: trt.scenes.sphere_grid(100000, w, h)}[scene_name](W, H)
+def short_run(trt, torch, dev, scene_name, spheres, W, H, S, steps, warmup, depth, backend_name, backend):
+    """A few steps of another scene at its own size on this GPU, after the timed region of the headline workload: value,
+    ms per step, the dominant kernel's launch time (HIP events on its launch stream), its lane-slot fraction and its HBM numbers."""
+    t_scene = time.perf_counter()
+    desc = {"random_spheres": trt.scenes.random_spheres, "sphere_grid": lambda w, h: trt.scenes.sphere_grid(spheres or 100000, w, h),
+            "sphere_field": lambda w, h: trt.scenes.sphere_field(spheres or 4_000_000, w, h)}[scene_name](W, H)
     world, cam = trt.world_from_description(desc)
     scene = world.get_bvh()
+    t_scene = time.perf_counter() - t_scene
     renderer = trt.Renderer(FRAME_SPP, 1, depth, False, desc["background"], seed=1, backend=backend)
     acc = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     ctr = torch.zeros(16, dtype=torch.int64, device=dev)
@@ -256,15 +278,18 @@ def short_run(trt, torch, dev, scene_name, W, H, S, steps, warmup, depth, backen
     n_launch = int(k_n.value)
     avg_ms = k_ms.value / n_launch if n_launch else None
     warnings = []
-    key = f"{scene_name}_{W}x{H}_d{depth}_spp{S}_{backend_name}"
+    key = f"{scene_name}{spheres or ''}_{W}x{H}_d{depth}_spp{S}_{backend_name}"
     rf = valu_roofline(key, avg_ms, rays / n_launch if n_launch else 0.0, warnings)
     kernel = trt.lib.trt_dominant_kernel(scene._h, C.byref(cam.pod), C.byref(renderer.params())).decode()
-    out = {"workload": f"{scene_name} {W}x{H}, depth {depth}, {S} spp per step (of 4096), {backend_name}, seed 1", "value": round(rays / elapsed / 1e6, 2),
+    info = scene.info()
+    out = {"workload": f"{scene_name}{' ' + str(spheres) + ' spheres' if spheres else ''} {W}x{H}, depth {depth}, {S} spp per step (of 4096), {backend_name}, seed 1",
+           "scene": {"primitives": info["num_spheres"] + info["num_quads"], "packed_bytes": info["device_bytes"], "build_s": round(t_scene, 2)},
+           "value": round(rays / elapsed / 1e6, 2),
            "unit": "Mray/s", "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 4), "rays": rays, "samples": samples,
            "roofline": {"kernel": kernel, "avg_launch_ms": round(avg_ms, 4) if avg_ms else None, "launches_timed": n_launch,
                         "frac": rf["frac"], "issue_frac": rf.get("issue_frac"), "mean_active_lanes": rf.get("mean_active_lanes"),
                         "cycles_per_valu_inst_per_simd": rf.get("cycles_per_valu_inst_per_simd"), "traffic": rf.get("traffic"),
-                        "pmc_key": key, "pmc_stale": rf["pmc_stale"], "warnings": warnings}}
+                        "hbm": rf.get("hbm"), "pmc_key": key, "pmc_stale": rf["pmc_stale"], "warnings": warnings}}
     del acc, scene, world
     return out
 
@@ -578,11 +603,11 @@ def main():
         except Exception as e:                                   # noqa: BLE001 - the bench line must still be printed
             parity = {"error": repr(e)}
     if rank == 0 and world_size == 1 and args.cpu_seconds > 0 and not args.no_other_scenes:
-        for name, ow, oh, ospp, osteps, owarm in OTHER_SCENES:
+        for name, ospheres, ow, oh, ospp, osteps, owarm in OTHER_SCENES:
             if name == args.scene and (ow, oh) == (W, H):
                 continue
             try:
-                other.append(short_run(trt, torch, dev, name, ow, oh, ospp, osteps, owarm, args.depth, args.backend, backend))
+                other.append(short_run(trt, torch, dev, name, ospheres, ow, oh, ospp, osteps, owarm, args.depth, args.backend, backend))
             except Exception as e:                               # noqa: BLE001
                 other.append({"workload": name, "error": repr(e)})
 

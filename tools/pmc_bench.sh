@@ -17,6 +17,7 @@ pass sq3 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH SQ_ACTI
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass grbm GRBM_GUI_ACTIVE
+pass tcc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum
 rocprofv3 --kernel-trace --stats --output-format csv -d $base/trace -- python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 $BENCH_ARGS > $base/trace.json 2> $base/trace.err || { echo "trace failed"; tail -3 $base/trace.err; exit 1; }
 python3 bench.py --steps 4 --warmup 1 --cpu-seconds 0 $BENCH_ARGS > $base/bench_plain.json 2> $base/bench_plain.err
 python3 - "$base" "$tag" <<'PY'
