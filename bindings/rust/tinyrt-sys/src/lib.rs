@@ -127,9 +127,7 @@ pub struct trt_tuning {
     pub mega_global_waves8: u32,
     pub wf_waves_per_simd: u32,
     pub wf_serve_min: u32,
-    pub no_top_cache: u32,
-    pub top_burst: u32,
-    pub reserved: [u32; 5],
+    pub reserved: [u32; 7],
 }
 
 #[repr(C)]
@@ -244,8 +242,6 @@ extern "C" {
     pub fn trt_scene_get_nodes(s: *const trt_scene, bbox6: *mut f32, prim: *mut i32, skip: *mut i32, cap: u32) -> c_int;
     pub fn trt_scene_get_cull_nodes(s: *const trt_scene, bbox6: *mut f32, prim: *mut i32, skip: *mut i32, cap: u32) -> c_int;
     pub fn trt_scene_get_compact_nodes(s: *const trt_scene, words4: *mut u32, cap: u32) -> c_int;
-    pub fn trt_scene_get_hybrid_nodes(s: *const trt_scene, top_words4: *mut u32, cap_top: u32, main_words4: *mut u32, cap_main: u32,
-                                      n_top: *mut u32, n_main: *mut u32) -> c_int;
 
     pub fn trt_camera_init(out: *mut trt_camera, focus_distance: f32, defocus_angle_deg: f32, position: trt_vec3,
                            look_at: trt_vec3, up: trt_vec3, vertical_fov_deg: f32, width: u32, height: u32) -> c_int;

@@ -34,9 +34,9 @@ extern "C" {
 #define TRT_ABI_VERSION 4   /* 2 (round 3): + trt_scene_trim, trt_streamed_launch_plan, trt_band_copy_plan
                              * 3 (round 4): tuning moved out of the process environment: trt_tuning (trt_render_params.tuning),
                              *              trt_scene_options + trt_scene_create_ex; trt_stats.gather_per_band
-                             * 4 (round 5): + trt_world_add_spheres, trt_scene_get_hybrid_nodes; trt_scene_options.top_nodes now sizes the
-                             *              top-in-LDS split of the 16-byte culling tree; trt_tuning.no_top_cache, .top_burst (were reserved[0..1]);
-                             *              d_counters[12..15] = shades by material kind.  No struct changed size or moved a field. */
+                             * 4 (round 5): + trt_world_add_spheres; trt_scene_options.top_nodes is ignored (the LDS cache of a large scene's upper
+                             *              tree levels is gone: measured slower in every form); d_counters[12..15] = shades by material kind.
+                             *              No struct changed size or moved a field. */
 
 enum trt_status {
     TRT_OK = 0,
@@ -97,8 +97,7 @@ typedef struct {
     float cull_prune;             /* culling tree: an inner node whose box is >= this share of its nearest kept ancestor's is dropped (0.5) */
     int32_t flat_walk;            /* lock-step leaf list instead of a tree walk: -1 = for at most 32 primitives (default), 0 never, 1 always */
     int32_t compact_nodes;        /* 16-byte f16 culling nodes: -1 = for scenes too large for LDS (default), 0 never, 1 always */
-    uint32_t top_nodes;           /* scenes walked from global memory: entries (<= 1280) of the 16-byte culling tree's upper part that every workgroup keeps
-                                     in LDS - its most-visited nodes, where half of all box steps fall (top-in-LDS walk); 0 = none: the plain walk */
+    uint32_t top_nodes;           /* ignored since ABI 4 (rounds 1-4: upper tree levels of a large scene cached in LDS; slower in every form measured) */
     uint64_t scratch_cap_bytes;   /* idle scratch (workspaces + context frames) kept per device between renders; default 32 GiB */
     uint32_t reserved[6];         /* zero */
 } trt_scene_options;
@@ -135,13 +134,6 @@ int trt_scene_get_cull_nodes(const trt_scene *s, float *bbox6, int32_t *prim, in
  * num_cull_nodes x 4 words: (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, link), link = skip index of an
  * inner node, or 0x80000000 | leaf sequence number.  Returns TRT_ERR_NOT_FOUND if the scene has no such array. */
 int trt_scene_get_compact_nodes(const trt_scene *s, uint32_t *words4, uint32_t cap);
-/* The same tree as the top-in-LDS walk reads it (trt_scene_options.top_nodes > 0): two arrays of such 16-byte nodes - `top` (what a workgroup
- * copies into LDS) and `main` (global memory) - walked by ONE cursor: bit 30 set = index into main, clear = index into top; a node's successor
- * when its box passes or it is a leaf is cursor + 1, else its link, which is a cursor value; nodes whose box is x in [+inf, +inf] are portals
- * (never pass; their link leads into the other array); the walk ends at cursor == n_top.  Either pointer may be NULL (sizes only).
- * Returns TRT_ERR_NOT_FOUND if the scene has no such split. */
-int trt_scene_get_hybrid_nodes(const trt_scene *s, uint32_t *top_words4, uint32_t cap_top, uint32_t *main_words4, uint32_t cap_main,
-                               uint32_t *n_top, uint32_t *n_main);
 
 /* ---- Camera (camera.rs:4-14, 17-56) ---- */
 typedef struct {
@@ -186,9 +178,7 @@ typedef struct {
     uint32_t mega_global_waves8;      /* megakernel on scenes in global memory: 8 waves per SIMD (0)        TRT_MINW8 */
     uint32_t wf_waves_per_simd;       /* wavefront backend: 0 = default                                     TRT_WF_MINW */
     uint32_t wf_serve_min;            /* wavefront backend: lanes that must wait before a refill; 0 = default (12)   TRT_WF_SERVE_MIN */
-    uint32_t no_top_cache;            /* 1: walk a scene that carries the top-in-LDS split (trt_scene_options.top_nodes) with the plain 16-byte-node walk (0)   TRT_NO_TOP_CACHE */
-    uint32_t top_burst;               /* top-in-LDS walk: box steps a lane may take out of LDS per round, while the wave's global loads are in flight; 0 = default (4)   TRT_TOP_BURST */
-    uint32_t reserved[5];             /* zero */
+    uint32_t reserved[7];             /* zero */
 } trt_tuning;
 void trt_tuning_default(trt_tuning *out);
 
@@ -296,10 +286,9 @@ int trt_tonemap_u8_device(const float *d_accum, uint32_t npixels, float gamma, u
 typedef struct {
     uint32_t scene_mode;              /* 0 scene read from global memory, 1 whole hot scene copied into LDS */
     uint32_t threads_per_workgroup, waves_per_simd, workgroups_per_cu;
-    uint32_t lds_bytes, scene_lds_bytes;      /* dynamic LDS per workgroup; the scene copy's share (walk 4: the copy of the tree's upper part) */
+    uint32_t lds_bytes, scene_lds_bytes;      /* dynamic LDS per workgroup; the scene copy's share */
     uint32_t leaf_slots, lds_leaf_stack, ray_pool;
-    uint32_t walk;                    /* 1 tree walk with LDS leaf stack, 2 lock-step leaf list, 3 16-byte nodes, 4 16-byte nodes with the tree's upper part in LDS,
-                                         5 tree walk with register slots */
+    uint32_t walk;                    /* 1 tree walk with LDS leaf stack, 2 lock-step leaf list, 3 16-byte nodes, 5 tree walk with register slots */
     uint32_t specialised;             /* 1: a kernel with the walk fixed at compile time */
     uint32_t has_kernel;              /* 0 would be a bug: no instantiation for the plan (the launch then fails, it never falls back) */
     uint32_t kernel_waves_per_simd, kernel_threads, kernel_walk /* 0 = chosen at run time */, kernel_ray_pool, kernel_counting;

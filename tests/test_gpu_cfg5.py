@@ -29,9 +29,7 @@ def test_cfg5_full_frame_bit_exact_against_the_oracle(trt, orc, cfg5):
     ow, ocam = orc.world_from_description(desc)
     cpu, cst = orc.render(ow, ocam, 1, DEPTH, desc["background"], seed=1, nthreads=16)
     frames = {}
-    for name, options, knobs in (("default", {}, {}), ("nodes32", {"compact_nodes": 0}, {}), ("two paths per lane", {}, {"dual_walk": 1}),
-                                 ("upper part in LDS, 320", {"top_nodes": 320}, {}), ("upper part in LDS, 640", {"top_nodes": 640}, {}),
-                                 ("upper part in LDS, 1280", {"top_nodes": 1280}, {}), ("plain walk", {"top_nodes": 0}, {})):
+    for name, options, knobs in (("default", {}, {}), ("nodes32", {"compact_nodes": 0}, {}), ("two paths per lane", {}, {"dual_walk": 1})):
         pw, pcam = trt.world_from_description(desc, **options)       # trt_scene_options: read when the scene is compiled
         info = pw.get_bvh().info()
         assert info["num_nodes"] == 200001 and info["num_spheres"] == 100001 and info["lds_bytes"] == 0

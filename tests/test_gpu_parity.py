@@ -121,31 +121,6 @@ def test_large_scene_traversed_from_global_memory(trt, orc):
         assert gst[k] == cst[k], k
 
 
-@pytest.mark.parametrize("top_nodes", [4, 37, 320, 640, 1280])
-def test_large_scene_with_the_trees_upper_part_in_lds(trt, orc, top_nodes):
-    """trt_scene_options.top_nodes: the top-in-LDS walk (rt_path.h walk_hybrid) - the 16-byte culling tree cut in two, its upper part in every
-    workgroup's LDS, one cursor over both parts, portals at the crossings - at every workgroup shape (256 / 512 / 1024 lanes) and at degenerate
-    budgets: same bits as the oracle and as the plain walk of the same scene; the other backends are untouched by the option."""
-    desc = trt.scenes.sphere_grid(4000, 96, 54)
-    ow, ocam = orc.world_from_description(desc)
-    cpu, cst = orc.render(ow, ocam, 4, 50, desc["background"], nthreads=8)
-    pw, pcam = trt.world_from_description(desc, top_nodes=top_nodes)
-    r = trt.Renderer(4, 1, 50, False, desc["background"])
-    plan = r.launch_plan(pcam, pw.get_bvh())
-    assert plan["walk"] == 4 and plan["threads_per_workgroup"] == (256 if top_nodes <= 320 else 512 if top_nodes <= 640 else 1024)
-    assert 0 < plan["scene_lds_bytes"] <= 16 * top_nodes
-    gpu = r.render(pcam, pw).data
-    assert_bit_equal(gpu, cpu, f"top-in-LDS walk, {top_nodes} entries")
-    assert r.last_stats["rays"] == cst["rays"]
-    for knobs in ({"no_top_cache": 1}, {"stragglers": 0}, {"stragglers": 30}, {"leaf_slots": 2}, {"leaf_slots": 1}, {"stream_batch_spp": 3}):
-        r2 = trt.Renderer(4, 1, 50, False, desc["background"])
-        r2.tuning = knobs
-        assert r2.launch_plan(pcam, pw.get_bvh())["walk"] == (3 if "no_top_cache" in knobs else 4), knobs
-        assert_bit_equal(r2.render(pcam, pw).data, cpu, f"top-in-LDS scene under {knobs}")
-    for backend in (0, 1):
-        assert_bit_equal(trt.Renderer(4, 1, 50, False, desc["background"], backend=backend).render(pcam, pw).data, cpu, f"backend {backend} on a scene with a top part")
-
-
 @pytest.mark.parametrize("wh", [(2, 2), (17, 5), (33, 47), (64, 16), (130, 3)])
 def test_ragged_image_sizes(trt, orc, wh):
     desc = trt.scenes.cornell(*wh)

@@ -338,9 +338,7 @@ def _check_plan(pl, stats, tag):
     (36 B per lane); the lock-step walk pushes two leaves per trip; every plan has an instantiation of the planned shape."""
     al = (pl["scene_lds_bytes"] + 15) & ~15
     assert pl["has_kernel"] == 1, tag
-    assert pl["kernel_threads"] == pl["threads_per_workgroup"] and pl["threads_per_workgroup"] in (256, 512, 768, 1024), tag
-    if pl["threads_per_workgroup"] == 1024:
-        assert pl["walk"] == 4, tag                                               # only the top-in-LDS walk shares an LDS copy among 16 waves
+    assert pl["kernel_threads"] == pl["threads_per_workgroup"] and pl["threads_per_workgroup"] in (256, 512, 768), tag
     assert 1 <= pl["leaf_slots"] <= 16, tag
     if pl["lds_leaf_stack"]:
         stacks = 2 if pl["dual_walk"] else 1                                      # two paths per lane: two leaf stacks per lane
@@ -355,11 +353,7 @@ def _check_plan(pl, stats, tag):
     if pl["walk"] == 2:
         assert pl["leaf_slots"] >= 2 and pl["lds_leaf_stack"], tag                # walk_flat: limit = stack + 64 * (slots - 2)
     if pl["walk"] == 3:
-        assert pl["scene_mode"] == 0 and pl["lds_leaf_stack"] and pl["scene_lds_bytes"] == 0, tag
-    if pl["walk"] == 4:                                                           # top-in-LDS walk: the copy of the tree's upper part sits where a scene copy would
-        assert pl["scene_mode"] == 0 and pl["lds_leaf_stack"] and pl["ray_pool"] and pl["specialised"] and not stats and not pl["dual_walk"], tag
-        assert 0 < pl["scene_lds_bytes"] <= 16 * 1280 and pl["scene_lds_bytes"] % 16 == 0 and pl["waves_per_simd"] == 8, tag
-        assert pl["workgroups_per_cu"] * pl["threads_per_workgroup"] == 8 * 256, tag          # full residency: the plan never trades waves for a bigger copy
+        assert pl["scene_mode"] == 0 and pl["lds_leaf_stack"], tag
     assert pl["kernel_counting"] == (1 if stats else 0), tag
     assert pl["kernel_walk"] == (pl["walk"] if pl["specialised"] else 0), tag
     if pl["kernel_waves_per_simd"] >= 5:
@@ -380,8 +374,6 @@ def test_streamed_launch_plan_invariants_for_every_scene_size_and_knob(trt):
     for n in (1, 2, 3, 31, 32, 33, 60, 120, 200, 330, 520, 800, 1500):           # LDS-resident sizes on both sides of every threshold
         scenes.append((f"grid{n}", trt.scenes.sphere_grid(n, 64, 48)))
     scenes.append(("grid4000", trt.scenes.sphere_grid(4000, 64, 48)))            # read from global memory
-    for top in (40, 300, 320, 600, 1280, 5000):                                  # ... with the top-in-LDS split of its 16-byte tree at every budget class
-        scenes.append((f"grid4000top{top}", trt.scenes.sphere_grid(4000, 64, 48)))
     knobs = {
         "stream_waves_per_simd": (None, 4, 5, 6, 7, 8, 9),
         "leaf_slots": (None, 1, 2, 3, 4, 8, 16, 64),
@@ -395,16 +387,11 @@ def test_streamed_launch_plan_invariants_for_every_scene_size_and_knob(trt):
     modes = set()
     for name, desc in scenes:
         for flat in ((None, 0) if name in ("cornell", "grid31") else (None,)):
-            opts = {} if flat is None else {"flat_walk": flat}
-            if "top" in name:
-                opts["top_nodes"] = int(name.split("top")[1])
-            w, cam = trt.world_from_description(desc, **opts)
+            w, cam = trt.world_from_description(desc, **({} if flat is None else {"flat_walk": flat}))
             scene = w.get_bvh()
             for combo in itertools.product(*knobs.values()):
-                if combo[-1] == 1 and not name.startswith("grid4000"):
+                if combo[-1] == 1 and name != "grid4000":
                     continue                                                      # two paths per lane exist for scenes in global memory only
-                if "top" in name and (combo[2] is not None or combo[4] is not None or combo[5] is not None):
-                    continue                                                      # (the split scenes: the knobs that interact with the plan's LDS arithmetic)
                 tn = {k: v for k, v in zip(knobs, combo) if v is not None}
                 for stats in (0, 1, 2):
                     pl = _plan(trt, scene, cam, tuning=tn, collect_stats=stats)
@@ -412,7 +399,6 @@ def test_streamed_launch_plan_invariants_for_every_scene_size_and_knob(trt):
                     modes.add((pl["scene_mode"], pl["walk"], pl["threads_per_workgroup"], pl["ray_pool"], pl["dual_walk"]))
                     n_checked += 1
     assert n_checked > 20000 and len(modes) >= 8, (n_checked, sorted(modes))
-    assert {m[2] for m in modes if m[1] == 4} == {256, 512, 1024}, sorted(modes)          # the top-in-LDS walk ran in all three workgroup shapes
 
 
 def test_default_plans_of_the_three_baseline_scenes(trt):
@@ -425,72 +411,6 @@ def test_default_plans_of_the_three_baseline_scenes(trt):
     w, cam = trt.world_from_description(trt.scenes.sphere_grid(4000, 64, 48))
     pl = _plan(trt, w.get_bvh(), cam)
     assert (pl["scene_mode"], pl["walk"], pl["waves_per_simd"], pl["ray_pool"], pl["specialised"]) == (0, 3, 8, 1, 1)
-
-
-def _half(words16):
-    return (words16 & 0xFFFF).astype(np.uint16).view(np.float16).astype(np.float32)
-
-
-def _slab16(w, o, inv, t_best):
-    """The 16-byte-node walks' slab test on one decoded node (rt_device.h slab_fast6_entry), in float32 like the device."""
-    lo = np.array([_half(w[0]), _half(w[0] >> 16), _half(w[1])], np.float32)
-    hi = np.array([_half(w[1] >> 16), _half(w[2]), _half(w[2] >> 16)], np.float32)
-    with np.errstate(invalid="ignore", over="ignore"):
-        a, b = (lo - o) * inv, (hi - o) * inv
-        tn = max(np.float32(0.001), np.minimum(a, b).max())
-        tf = min(np.float32(t_best), np.maximum(a, b).min())
-    return not (tf <= tn)
-
-
-@pytest.mark.parametrize("budget", [4, 9, 100, 320, 1280])
-def test_top_in_lds_split_walks_like_the_compact_tree(trt, budget):
-    """trt_scene_options.top_nodes: the 16-byte culling tree cut into `top` (LDS) and `main` (global memory) with cursor links and portals
-    (scene_host.cpp build_hybrid).  Replayed here on the host for random rays: the cursor walk steps the same real nodes in the same order and
-    puts the same leaves aside as the walk over the compact tree; portals never pass; `top` respects the budget.  (C++ twin under ASan:
-    tests/native/scene_host_check.cpp.)"""
-    desc = trt.scenes.sphere_grid(3000, 32, 24)
-    w, _ = trt.world_from_description(desc, top_nodes=budget)
-    scene = w.get_bvh()
-    lo, hi, link = scene.compact_nodes()
-    n = len(link)
-    compact = np.zeros((n, 4), np.uint32)
-    h = np.concatenate([lo, hi], axis=1).view(np.uint16).astype(np.uint32)        # lo.x lo.y lo.z hi.x hi.y hi.z
-    compact[:, 0], compact[:, 1], compact[:, 2], compact[:, 3] = h[:, 0] | h[:, 1] << 16, h[:, 2] | h[:, 3] << 16, h[:, 4] | h[:, 5] << 16, link
-    top, main = scene.hybrid_nodes()
-    assert 0 < len(top) <= budget and len(top) + len(main) >= n
-    MAIN = 0x40000000
-    rng = np.random.default_rng(budget)
-    for r in range(40):
-        o = rng.uniform(-40, 40, 3).astype(np.float32)
-        d = rng.uniform(-1, 1, 3).astype(np.float32)
-        d[np.abs(d) < 1e-3] = 1e-3
-        inv = (np.float32(1.0) / d).astype(np.float32)
-        t_best = np.float32(np.inf if r % 3 == 0 else rng.uniform(1.0, 80.0))
-        a_nodes, a_leaves, i = [], [], 0
-        while i < n:
-            q = compact[i]
-            p, leaf = _slab16(q, o, inv, t_best), bool(q[3] >> 31)
-            a_nodes.append(tuple(q[:3]))
-            if p and leaf:
-                a_leaves.append(int(q[3] & 0x7FFFFFFF))
-            i = i + 1 if (p or leaf) else int(q[3])
-        b_nodes, b_leaves, cur, steps = [], [], 0, 0
-        while cur != len(top):
-            steps += 1
-            assert steps < 4 * n + 16, "the cursor walk does not end"
-            q = main[cur & ~MAIN] if cur & MAIN else top[cur]
-            p, leaf = _slab16(q, o, inv, t_best), bool(q[3] >> 31)
-            if (q[0], q[1], q[2]) == (0x7C00, 0x7C00 << 16, 0):
-                assert not p and not leaf, "a portal passed"
-                cur = int(q[3])
-                continue
-            b_nodes.append(tuple(q[:3]))
-            if p and leaf:
-                b_leaves.append(int(q[3] & 0x7FFFFFFF))
-            cur = cur + 1 if (p or leaf) else int(q[3])
-        assert a_nodes == b_nodes and a_leaves == b_leaves, r
-    assert trt.world_from_description(desc)[0].get_bvh().hybrid_nodes() is None             # no budget, no split
-    assert trt.world_from_description(trt.scenes.cornell(8, 8), top_nodes=64)[0].get_bvh().hybrid_nodes() is None      # a scene walked from LDS has none either
 
 
 @pytest.mark.parametrize("height", [1, 15, 16, 17, 31, 32, 33, 250, 500, 1080, 2048, 2160])
@@ -559,7 +479,7 @@ def test_tuning_and_scene_option_defaults(trt):
     t = trt.tuning().as_dict()
     assert (t["stream_batch_spp"], t["radiance_gb"], t["lds_leaf_stack"], t["ray_pool"], t["stragglers"], t["lds_stragglers"]) == (8, 16, 1, 1, 8, 8)
     assert all(t[k] == 0 for k in ("stream_waves_per_simd", "stream_big_threads", "leaf_slots", "dual_walk", "runtime_walk", "xcd_remap",
-                                   "mega_waves_per_simd", "mega_threads", "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min", "no_top_cache", "top_burst"))
+                                   "mega_waves_per_simd", "mega_threads", "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min"))
     o = trt.scene_options()
     assert abs(o.cull_prune - 0.5) < 1e-7 and (o.flat_walk, o.compact_nodes, o.top_nodes, o.scratch_cap_bytes) == (-1, -1, 0, 32 << 30)
     with pytest.raises(TypeError):
@@ -576,7 +496,7 @@ def test_tuning_and_scene_option_defaults(trt):
 
 
 @pytest.mark.parametrize("options", [dict(cull_prune=0.9), dict(cull_prune=0.2), dict(flat_walk=0), dict(compact_nodes=1), dict(top_nodes=63),
-                                     dict(cull_prune=0.3, compact_nodes=1, flat_walk=1, top_nodes=31), dict(compact_nodes=1, top_nodes=640)])
+                                     dict(cull_prune=0.3, compact_nodes=1, flat_walk=1, top_nodes=31)])
 def test_scene_options_are_placement_only(trt, options):
     """Whatever trt_scene_options say, the reference tree is the reference's node for node and the culling tree keeps the reference's leaf
     sequence with the leaves' exact boxes - the two facts the bit-identical hits rest on; only inner nodes and layout move."""

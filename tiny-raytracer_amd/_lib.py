@@ -76,8 +76,8 @@ class Tuning(C.Structure):
     """tinyrt.h trt_tuning: scheduling / placement knobs of a render; every value renders the same frame."""
     FIELDS = ("stream_waves_per_simd", "stream_big_threads", "stream_batch_spp", "radiance_gb", "leaf_slots", "lds_leaf_stack", "ray_pool",
               "stragglers", "lds_stragglers", "dual_walk", "runtime_walk", "xcd_remap", "mega_waves_per_simd", "mega_threads",
-              "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min", "no_top_cache", "top_burst")
-    _fields_ = [(n, C.c_uint32) for n in FIELDS] + [("reserved", C.c_uint32 * 5)]
+              "mega_global_waves8", "wf_waves_per_simd", "wf_serve_min")
+    _fields_ = [(n, C.c_uint32) for n in FIELDS] + [("reserved", C.c_uint32 * 7)]
 
     def as_dict(self):
         return {n: getattr(self, n) for n in self.FIELDS}
@@ -115,7 +115,6 @@ SIGNATURES = {
     "trt_world_add_material": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(Material)]),
     "trt_world_get_material": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint32)]),
     "trt_world_add_sphere": (C.c_int, [C.c_void_p, Vec3, C.c_float, C.c_uint32]),
-    "trt_scene_get_hybrid_nodes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "trt_world_add_spheres": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]),
     "trt_world_add_quad": (C.c_int, [C.c_void_p, Vec3, Vec3, Vec3, C.c_uint32]),
     "trt_world_num_geometries": (C.c_int, [C.c_void_p]),

@@ -126,18 +126,6 @@ class Scene:
         return h[:, :3], h[:, 3:], words[:, 3].copy()
 
 
-    def hybrid_nodes(self):
-        """The top-in-LDS split of the 16-byte culling tree (scene option top_nodes > 0): (top[n_top, 4], main[n_main, 4]) uint32 words, or None."""
-        nt, nm = C.c_uint32(0), C.c_uint32(0)
-        rc = lib.trt_scene_get_hybrid_nodes(self._h, None, 0, None, 0, C.byref(nt), C.byref(nm))
-        if rc == _lib.ERR_NOT_FOUND:
-            return None
-        check(rc)
-        top, main = np.zeros((nt.value, 4), np.uint32), np.zeros((max(nm.value, 1), 4), np.uint32)
-        check(lib.trt_scene_get_hybrid_nodes(self._h, top.ctypes.data, nt.value, main.ctypes.data, nm.value, None, None))
-        return top, main[:nm.value]
-
-
 class World:
     def __init__(self):
         self._h = C.c_void_p()

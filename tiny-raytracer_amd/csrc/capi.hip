@@ -161,7 +161,7 @@ const Defaults& defaults() {
         u32("TRT_STREAM_MINW", t.stream_waves_per_simd); u32("TRT_BIG_THREADS", t.stream_big_threads); u32("TRT_STREAM_BATCH_SPP", t.stream_batch_spp);
         u32("TRT_RADIANCE_GB", t.radiance_gb); u32("TRT_LEAF_SLOTS", t.leaf_slots); u32("TRT_LDS_LEAF_STACK", t.lds_leaf_stack);
         u32("TRT_RAY_POOL", t.ray_pool); u32("TRT_STRAGGLERS", t.stragglers); u32("TRT_LDS_STRAGGLERS", t.lds_stragglers);
-        u32("TRT_DUAL_WALK", t.dual_walk); u32("TRT_NO_TOP_CACHE", t.no_top_cache); u32("TRT_TOP_BURST", t.top_burst); u32("TRT_RUNTIME_WALK", t.runtime_walk); u32("TRT_XCD_REMAP", t.xcd_remap);
+        u32("TRT_DUAL_WALK", t.dual_walk); u32("TRT_RUNTIME_WALK", t.runtime_walk); u32("TRT_XCD_REMAP", t.xcd_remap);
         u32("TRT_MINW", t.mega_waves_per_simd); u32("TRT_MEGA_THREADS", t.mega_threads); u32("TRT_MINW8", t.mega_global_waves8);
         u32("TRT_WF_MINW", t.wf_waves_per_simd); u32("TRT_WF_SERVE_MIN", t.wf_serve_min);
         trt_scene_options& o = x.scene;
@@ -171,7 +171,6 @@ const Defaults& defaults() {
         }
         if (const char* e = env("TRT_FLAT_WALK")) o.flat_walk = atoi(e) ? 1 : 0;
         if (const char* e = env("TRT_COMPACT_NODES")) o.compact_nodes = atoi(e) ? 1 : 0;
-        u32("TRT_TOP_NODES", o.top_nodes);
         if (const char* e = env("TRT_SCRATCH_CAP_MB")) o.scratch_cap_bytes = (uint64_t)strtoull(e, nullptr, 10) << 20;
         return x;
     }();
@@ -485,7 +484,6 @@ int to_render_args(const trt_camera* cam, const trt_render_params* p, RenderArgs
     ra.lds_leaf_stack = tn.lds_leaf_stack;                 // 0 off, 1 where it costs no occupancy, 2 always
     ra.xcd_aware = tn.xcd_remap ? 1u : 0u;                 // off: contiguous image regions per XCD measured 2x slower (load imbalance)
     ra.stragglers = tn.stragglers;                         // profiles/r03_stragglers_sweep.txt
-    ra.top_burst = tn.top_burst;                           // (launch_streamed fills in the default)
     ra.ref_tree = p->collect_stats == 1 ? 1u : 0u;      // 1: counters comparable with the CPU path; 2: count the culling tree's own tests
     return TRT_OK;
 }
@@ -771,24 +769,6 @@ int trt_scene_get_compact_nodes(const trt_scene* s, uint32_t* words4, uint32_t c
     if (L.off_compact == 0u) return fail(TRT_ERR_NOT_FOUND, "scene has no compact node array (it is walked from LDS)");
     if (cap < L.n_cull_nodes) return fail(TRT_ERR_INVALID_ARG, "buffer too small");
     memcpy(words4, s->host.blob.data() + 16u * (size_t)L.off_compact, 16u * (size_t)L.n_cull_nodes);
-    return TRT_OK;
-}
-
-int trt_scene_get_hybrid_nodes(const trt_scene* s, uint32_t* top_words4, uint32_t cap_top, uint32_t* main_words4, uint32_t cap_main,
-                               uint32_t* n_top, uint32_t* n_main) {
-    if (!s) return fail(TRT_ERR_INVALID_ARG, "null argument");
-    const SceneLayout& L = s->host.layout;
-    if (L.n_hyb_top == 0u) return fail(TRT_ERR_NOT_FOUND, "scene has no top-in-LDS split (trt_scene_options.top_nodes is 0, or it is walked from LDS)");
-    if (n_top) *n_top = L.n_hyb_top;
-    if (n_main) *n_main = L.n_hyb_main;
-    if (top_words4) {
-        if (cap_top < L.n_hyb_top) return fail(TRT_ERR_INVALID_ARG, "buffer too small");
-        memcpy(top_words4, s->host.blob.data() + 16u * (size_t)L.off_hyb_top, 16u * (size_t)L.n_hyb_top);
-    }
-    if (main_words4) {
-        if (cap_main < L.n_hyb_main) return fail(TRT_ERR_INVALID_ARG, "buffer too small");
-        memcpy(main_words4, s->host.blob.data() + 16u * (size_t)L.off_hyb_main, 16u * (size_t)L.n_hyb_main);
-    }
     return TRT_OK;
 }
 

@@ -33,7 +33,6 @@ struct RenderArgs {
     uint32_t ref_tree;           // 1: walk the reference tree (counting kernels: counters comparable with the oracle)
     uint32_t stragglers;         // streamed walks of scenes in global memory: a round's walk phase ends once at most this many lanes of the wave still walk
                                  // (they carry their walk into the next round); 0 = every walk runs to its end (rt_path.h walk_compact)
-    uint32_t top_burst;          // top-in-LDS walk: steps a lane may take out of LDS while the wave's global node loads are in flight (rt_path.h box_loop_hybrid)
 };
 
 // The built-in scheduling defaults (tinyrt.h trt_tuning; each a measured optimum, DESIGN.md "Tuning").  They live in THIS header -
@@ -50,8 +49,6 @@ inline trt_tuning tuning_builtin() {
     t.ray_pool = 1;
     t.stragglers = 8;                 // profiles/r03_stragglers_sweep.txt
     t.lds_stragglers = 8;
-    t.top_burst = 0;                  // 4
-    t.no_top_cache = 0;               // a scene compiled with a top part (trt_scene_options.top_nodes) is walked with it in LDS
     t.dual_walk = 0;                  // two paths per lane: +2 % at 6 waves per SIMD, -7 % at 8 (profiles/r04_dual_walk_sweep.txt): not the default
     t.runtime_walk = 0;
     t.xcd_remap = 0;
@@ -75,8 +72,7 @@ inline uint32_t rng_seed_key(uint32_t seed) {
 enum { CTR_SAMPLES = 0, CTR_RAYS, CTR_NODE, CTR_SPHERE, CTR_QUAD_PLANE, CTR_QUAD_INSIDE, CTR_SHADE, CTR_PEND = 7,
        CTR_W_ROUNDS = 8, CTR_W_STEPS, CTR_W_LEAF, CTR_W_GEN, CTR_SHADE_KIND = 12, CTR_COUNT = 16 };
 
-// scene.h kLdsSceneMaxBytes: hot blobs up to that size are copied whole into LDS; larger scenes are read from global memory (the
-// top-in-LDS walk keeps the upper part of their 16-byte culling tree in LDS: StreamLaunchPlan::top_lds_bytes, not part of the "scene copy").
+// scene.h kLdsSceneMaxBytes: hot blobs up to that size are copied whole into LDS; larger scenes are read from global memory.
 inline int scene_mode(const SceneLayout& L) { return L.hot_bytes <= kLdsSceneMaxBytes ? 1 : 0; }
 inline uint32_t scene_lds_bytes(const SceneLayout& L) { return scene_mode(L) == 1 ? L.hot_bytes : 0u; }
 
@@ -115,7 +111,6 @@ struct StreamLaunchPlan {
     uint32_t wg_per_cu, slots;              // resident workgroups per CU; postponed-leaf slots per lane
     bool lds_stack, flat, compact, pool, specialised;
     bool dual;                              // two paths per lane (stream_dual_kernel): two leaf stacks per lane
-    bool hybrid;                            // top-in-LDS walk (rt_path.h walk_hybrid): scene_lds_bytes is the workgroup's copy of the tree's upper part
     int walk;                               // WALK_* the kernel will run
     size_t lds_bytes, scene_lds_bytes;      // dynamic LDS per workgroup; the scene copy's share of it
     const void* kernel;                     // the instantiation (nullptr: none - a bug, launch_streamed fails)

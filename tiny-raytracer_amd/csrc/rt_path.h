@@ -15,8 +15,12 @@ extern __shared__ float4 g_lds[];          // dynamic LDS: [scene copy (LDS vari
 // ------------------------------------------------------------------------------------------------
 // Scene access: LDS copy or global blob, same element offsets (scene.h).
 // ------------------------------------------------------------------------------------------------
-enum { MODE_GLOBAL = 0,      // scene read through L1/L2 (the top-in-LDS walk keeps the upper part of its 16-byte culling tree in LDS: walk_hybrid)
+enum { MODE_GLOBAL = 0,      // scene read through L1/L2
        MODE_LDS = 1 };       // the whole hot part of the blob (culling tree, primitives, materials) copied into LDS
+// (A third mode - the upper part of a large scene's tree in LDS - was built twice and lost twice: round 4's level-order top levels of the 32-byte
+// tree, "slower at every size", and round 5's split of the 16-byte tree with a hand-written exec-mask loop, 7-10 % slower one step per trip and twice
+// as slow with LDS lanes running ahead.  The walk of a scene in global memory is bound by VALU issue; LDS hits spare it nothing and the split
+// costs instructions.  DESIGN_HISTORY.md B.5, profiles/r05_top_in_lds_walk_ab*.txt, tools/archive/top_in_lds_walk/.)
 
 template <int MODE>
 struct SceneAcc {
@@ -832,155 +836,13 @@ TRT_DEV void walk_compact2(const SceneAcc<MODE>& sc, const uint4* __restrict__ n
     doneA = iA >= n; doneB = iB >= n;
 }
 
-
-// ------------------------------------------------------------------------------------------------------------------
-// Top-in-LDS walk (round 5): walk_compact with the UPPER PART of the 16-byte tree in LDS.  The culling tree is shallow and wide
-// (pruned inner nodes hang their children on the nearest kept ancestor), and a fixed-order walk steps a node's children one after the other
-// whatever their boxes say: on the 100 k-sphere scene 52 % of all box steps fall on the tree's 489 most-visited nodes (7.6 KB as 16-byte
-// nodes) and 65 % on 1 378 (profiles/r05_top_share_model.txt).  Those come out of LDS here (ds_read_b128) instead of through the texture
-// addresser and L1, which is what the plain walk queues for.  The scene carries the tree split in two arrays (scene.h "hybrid
-// layout", scene_host.cpp build_hybrid): `top` - copied into the front of the workgroup's LDS when the kernel starts - and `main` in global
-// memory; ONE cursor walks both (bit 30 = "index into main"), a node's link is a cursor value, and the crossings are ordinary nodes whose
-// box nothing passes ("portals"), so the loop body is walk_compact's plus the exec-mask split of the load: lanes whose cursor has bit 30
-// set take global_load_dwordx4, the others ds_read_b128, into the SAME registers.  The walk is over when the cursor equals `end` (the
-// number of entries of `top`).  Same nodes in the same order with the same boxes as walk_compact: the portals add box steps, never a leaf.
-// (Round 4's MODE_HYBRID - the first levels of the 32-byte tree placed level by level and chosen by `i < n_top` in the run-time walk at
-// launch bound 1 - was "slower at every size" and is gone.)
-// ------------------------------------------------------------------------------------------------------------------
-// One box step on a 16-byte node held in D0..D3 (f16 pairs + link) for the lanes in exec: decode, slab test, next cursor, leaf put aside.
-// Temporaries v52-v56; %[m0] / %[m1] scratch masks; exec is the same on exit as on entry.
-#define TRT_HYBRID_STEP(D0, D1, D2, D3)                                                                                                        \
-        "v_cvt_f32_f16_e32 v52, " D0 "\n"                                                                 /* lo.x */                        \
-        "v_cvt_f32_f16_sdwa " D0 ", " D0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* lo.y */                        \
-        "v_cvt_f32_f16_e32 v53, " D1 "\n"                                                                 /* lo.z */                        \
-        "v_cvt_f32_f16_sdwa " D1 ", " D1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* hi.x */                        \
-        "v_cvt_f32_f16_e32 v54, " D2 "\n"                                                                 /* hi.y */                        \
-        "v_cvt_f32_f16_sdwa " D2 ", " D2 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* hi.z */                        \
-        "v_sub_f32_e32 v52, v52, %[ox]\n v_sub_f32_e32 " D1 ", " D1 ", %[ox]\n v_sub_f32_e32 " D0 ", " D0 ", %[oy]\n"                      \
-        "v_sub_f32_e32 v54, v54, %[oy]\n v_sub_f32_e32 v53, v53, %[oz]\n v_sub_f32_e32 " D2 ", " D2 ", %[oz]\n"                            \
-        "v_mul_f32_e32 v52, v52, %[ix]\n v_mul_f32_e32 " D1 ", " D1 ", %[ix]\n v_mul_f32_e32 " D0 ", " D0 ", %[iy]\n"                      \
-        "v_mul_f32_e32 v54, v54, %[iy]\n v_mul_f32_e32 v53, v53, %[iz]\n v_mul_f32_e32 " D2 ", " D2 ", %[iz]\n"                            \
-        "v_min_f32_e32 v55, v52, " D1 "\n v_max_f32_e32 v52, v52, " D1 "\n v_min_f32_e32 v56, " D0 ", v54\n"                               \
-        "v_max_f32_e32 " D0 ", " D0 ", v54\n v_max_f32_e32 v55, v55, v56\n v_min_f32_e32 v56, v53, " D2 "\n"                               \
-        "v_max_f32_e32 v53, v53, " D2 "\n v_min_f32_e32 v52, v52, " D0 "\n v_max3_f32 v55, v55, v56, %[tmin]\n"      /* start */           \
-        "v_min3_f32 v52, %[tb], v52, v53\n"                                                                           /* end */             \
-        "v_cmp_nle_f32_e32 vcc, v52, v55\n"                                                         /* pass = !(end <= start) */            \
-        "v_cmp_gt_i32_e64 %[m0], 0, " D3 "\n"                                                       /* leaf: sign bit of the link */        \
-        "s_or_b64 %[m1], vcc, %[m0]\n"                                                                                                     \
-        "v_add_u32_e32 v56, 1, %[i]\n"                                                                                                     \
-        "v_cndmask_b32_e64 %[i], " D3 ", v56, %[m1]\n"                                              /* cursor + 1, or the link */           \
-        "s_and_b64 %[m1], vcc, %[m0]\n"                                                             /* a leaf whose coarse box passes: */   \
-        "s_and_saveexec_b64 %[m0], %[m1]\n"                                                                                                \
-        "v_and_b32_e32 v54, 0x7fffffff, " D3 "\n"                                                                                          \
-        "ds_write2_b32 %[top], v54, v55 offset1:1\n"                                                /*   (leaf number, coarse start) */     \
-        "v_add_u32_e32 %[top], 0x200, %[top]\n"                                                                                            \
-        "s_mov_b64 exec, %[m0]\n"
-
-// The box-step loop of walk_hybrid.  A ROUND: the lanes whose cursor stands in `main` request their node from global memory; while that load is
-// in flight the lanes whose cursor stands in `top` take up to `burst` steps out of LDS (a node is there in ~100 cycles, a global one in ~1000 under
-// load); then the global lanes take their step.  A lane that crosses from one array into the other waits for the next round.  (The first form
-// stepped every lane once per trip whichever memory its node came from: the LDS lanes idled behind the global ones, the trips per ray did not
-// change, and the split's eight instructions made it 7-10 % SLOWER than the plain walk: profiles/r05_top_in_lds_walk_ab.txt.)
-// The round ends the loop when at most `few` lanes can still step (resumable walks), 0 = none.  Each lane steps its own nodes in their order.
-TRT_DEV float2* box_loop_hybrid(Trav& tr, const V3& o, const uint4* __restrict__ main16, uint32_t top_lds, float2* stk, float2* limit, uint32_t end, uint32_t few,
-                                uint32_t burst) {
-    const uint32_t stk_off = lds_offset(stk);
-    uint32_t top = stk_off;
-    const uint32_t lim = lds_offset(limit);
-    unsigned long long saved, m0, m1, m_main, m_lds;
-    uint32_t cnt, k;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n"
-        "1:\n"
-        "v_cmp_ne_u32_e32 vcc, %[end], %[i]\n"               // the walk is not over
-        "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // the leaf stack is not full
-        "s_and_b64 %[m0], vcc, %[m0]\n"                      // lanes that can step
-        "s_bcnt1_i32_b64 %[cnt], %[m0]\n"
-        "s_cmp_le_u32 %[cnt], %[few]\n"                      // at most `few` of them (0: none): leave
-        "s_cbranch_scc1 2f\n"
-        "v_cmp_le_u32_e32 vcc, 0x40000000, %[i]\n"           // cursor in `main` (kHybMainBit)
-        "s_and_b64 %[mm], %[m0], vcc\n"
-        "s_andn2_b64 %[ml], %[m0], vcc\n"
-        "s_mov_b64 exec, %[mm]\n"                            // global lanes: request the node (nothing moves if there is none)
-        "v_lshlrev_b32_e32 v52, 4, %[i]\n"                   //   byte offset; bit 30 of the cursor falls off the top
-        "global_load_dwordx4 v[48:51], v52, %[nodes]\n"
-        "s_mov_b32 %[k], %[burst]\n"
-        "3:\n"                                               // LDS lanes: up to `burst` steps while that load is in flight
-        "s_mov_b64 exec, %[ml]\n"
-        "s_cbranch_execz 4f\n"
-        "v_lshl_add_u32 v53, %[i], 4, %[ldsbase]\n"
-        "ds_read_b128 v[44:47], v53\n"
-        "s_waitcnt lgkmcnt(0)\n"
-        TRT_HYBRID_STEP("v44", "v45", "v46", "v47")
-        "v_cmp_ne_u32_e32 vcc, %[end], %[i]\n"               // still stepping in `top`: walk not over, stack not full, cursor below the main bit
-        "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"
-        "s_and_b64 %[m1], vcc, %[m0]\n"
-        "v_cmp_gt_u32_e32 vcc, 0x40000000, %[i]\n"
-        "s_and_b64 %[ml], %[m1], vcc\n"
-        "s_sub_u32 %[k], %[k], 1\n"
-        "s_cmp_lg_u32 %[k], 0\n"
-        "s_cbranch_scc1 3b\n"
-        "4:\n"
-        "s_mov_b64 exec, %[mm]\n"
-        "s_waitcnt vmcnt(0)\n"
-        "s_cbranch_execz 5f\n"
-        TRT_HYBRID_STEP("v48", "v49", "v50", "v51")
-        "5:\n"
-        "s_mov_b64 exec, %[sv]\n"
-        "s_branch 1b\n"
-        "2:\n"
-        : [i] "+v"(tr.i), [top] "+v"(top), [sv] "=&s"(saved), [m0] "=&s"(m0), [m1] "=&s"(m1), [mm] "=&s"(m_main), [ml] "=&s"(m_lds), [cnt] "=&s"(cnt), [k] "=&s"(k)
-        : [end] "s"(end), [few] "s"(few), [burst] "s"(burst), [nodes] "s"(main16), [ldsbase] "s"(top_lds), [lim] "v"(lim), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z),
-          [ix] "v"(tr.inv.x), [iy] "v"(tr.inv.y), [iz] "v"(tr.inv.z), [tb] "v"(tr.t_best), [tmin] "s"(kTMin)
-        : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
-    return stk + ((top - stk_off) >> 3);
-}
-
-// `lds_top`: the workgroup's LDS copy of the scene's `top` array (the front of dynamic LDS); `main16`: the scene's `main` array.  Resumable like
-// walk_compact (a parked cursor keeps its bit 30).
-template <int MODE, bool STATS>
-TRT_DEV bool walk_hybrid(const SceneAcc<MODE>& sc, const uint4* lds_top, const uint4* __restrict__ main16, const float4* __restrict__ leaf_list,
-                         const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots, uint32_t stragglers = 0u, uint32_t entered = 64u,
-                         uint32_t burst = 4u) {
-    const uint32_t end = sc.L.n_hyb_top;
-    float2* const limit = stk + 64u * slots;
-    const uint32_t few = stragglers < entered ? stragglers : entered - 1u;             // see walk_fast_lds
-    for (;;) {
-        float2* top = stk;
-        if constexpr (kAsmBoxLoop && !STATS) {
-            top = box_loop_hybrid(tr, ray.o, main16, lds_offset(lds_top), stk, limit, end, few, burst);
-        } else
-        while (tr.i != end && top != limit) {
-            const uint4 q = (tr.i & kHybMainBit) ? main16[tr.i & ~kHybMainBit] : lds_top[tr.i];
-            if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
-            const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
-            float start;
-            const bool pass = slab_fast6_entry(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), ray.o, tr.inv,
-                                               kTMin, tr.t_best, start);
-            const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
-            if (pass && is_leaf) {
-                *top = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), start);
-                top += 64;
-            }
-            tr.i = (pass || is_leaf) ? tr.i + 1u : q.w;
-            if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= few) break;      // see walk_fast_lds
-        }
-        TRT_CLK(ctr, 1);
-        if (top == stk && tr.i == end) return true;
-        if (top != stk) leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { compact_leaf_test<MODE, STATS>(sc, leaf_list, ray, tr, leaf, ctr); });
-        TRT_CLK(ctr, 2);
-        if (tr.i == end) return true;
-        if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= few) { trav_park(stk, tr); return false; }      // resumable: see walk_fast_lds
-    }
-}
-
 constexpr uint32_t kLdsLeafSlotsMax = 16; // most slots per lane of the LDS leaf stack (8 bytes each)
 
 // Which walk a kernel instantiation runs.  WALK_RUNTIME picks by the launch arguments (every knob combination; counting
 // kernels); the others fix the walk at compile time, which is what the production launches use: the kernel then holds ONE
 // walk instead of five, with the SGPRs, VGPRs and instruction-cache footprint of one (stream_pool_kernel on Cornell:
 // 6849 lines of ISA, 44 spilled SGPRs and 16 spilled VGPRs with the runtime choice).
-enum { WALK_RUNTIME = 0, WALK_LDS_STACK = 1, WALK_FLAT = 2, WALK_COMPACT = 3, WALK_HYBRID = 4, WALK_REGS = 5 };
+enum { WALK_RUNTIME = 0, WALK_LDS_STACK = 1, WALK_FLAT = 2, WALK_COMPACT = 3, WALK_REGS = 5 };
 
 // Whole walk for one lane.  Returns the primitive reference (PRIM_NONE on a miss) and its t.  Postponed leaves go to
 // `lds_stack` (this lane's slot 0 of a `leaf_slots`-deep LDS stack) if the kernel has one, else into registers:
@@ -1019,12 +881,10 @@ TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_
 // walk is complete (tr.t_best / tr.prim_best).
 template <int MODE, bool STATS, int WALK>
 TRT_DEV bool closest_hit_resume(const SceneAcc<MODE>& sc, const Ray& ray, Trav& tr, Counters<STATS>& ctr, uint32_t leaf_slots, float2* lds_stack,
-                                const float4* __restrict__ leaf_list, const uint4* __restrict__ nodes16, uint32_t stragglers, uint32_t entered, uint32_t burst = 4u) {
-    static_assert(WALK == WALK_COMPACT || WALK == WALK_LDS_STACK || WALK == WALK_HYBRID, "only the per-lane tree walks with an LDS leaf stack can be left and resumed");
+                                const float4* __restrict__ leaf_list, const uint4* __restrict__ nodes16, uint32_t stragglers, uint32_t entered) {
+    static_assert(WALK == WALK_COMPACT || WALK == WALK_LDS_STACK, "only the per-lane tree walks with an LDS leaf stack can be left and resumed");
     if (__builtin_expect(!tr.ref, 1)) {
-        // WALK_HYBRID: `nodes16` is the scene's `main` array; its `top` array is the front of the workgroup's dynamic LDS (staged by the kernel)
-        if constexpr (WALK == WALK_HYBRID) return walk_hybrid<MODE, STATS>(sc, reinterpret_cast<const uint4*>(g_lds), nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots, stragglers, entered, burst);
-        else if constexpr (WALK == WALK_COMPACT) return walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots, stragglers, entered);
+        if constexpr (WALK == WALK_COMPACT) return walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots, stragglers, entered);
         else return walk_fast_lds<MODE, STATS>(sc, ray, tr, ctr, lds_stack, leaf_slots, stragglers, entered);
     }
     closest_hit_ref<MODE, STATS>(sc, ray, tr, ctr);

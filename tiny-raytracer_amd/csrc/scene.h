@@ -34,12 +34,6 @@ struct F4 { float x, y, z, w; };            // 16-byte plane element (float4 on 
 
 enum : uint32_t { PRIM_NONE = 0xFFFFFFFFu, PRIM_QUAD_BIT = 0x40000000u, PRIM_INDEX_MASK = 0x3FFFFFFFu,
                   NODE_INNER_BIT = 0x80000000u };         // node link: inner -> NODE_INNER_BIT | first child; leaf -> primitive ref
-// Top-in-LDS walk of scenes too large for LDS (round 5; rt_path.h walk_hybrid): entries of the culling tree's upper part that every
-// workgroup keeps in LDS (trt_scene_options.top_nodes; 0 = none: the plain 16-byte-node walk).  A workgroup's share of the CU's 160 KB
-// bounds it: 320 entries with 256 lanes per workgroup, 640 with 512, 1280 with 1024 (streamed.hip streamed_launch_plan).
-constexpr uint32_t kHybridTopMax = 1280;
-constexpr uint32_t kHybridTopDefault = 0;
-constexpr uint32_t kHybMainBit = 0x40000000u;             // cursor / link: index into the `main` array (global memory); clear: into `top` (LDS)
 
 struct Geometry {
     uint32_t kind;                           // 0 sphere, 1 quad
@@ -73,13 +67,10 @@ struct World {
 //   [leaf list: 2 per leaf (+ kLeafListPad copies of the last)] the leaves of the trees in walk order, same node format (skip = successor)
 //   [compact culling tree: 1 per node] scenes too large for LDS only: (f16 lo.xy | lo.z,hi.x | hi.yz | skip or LEAF|k),
 //       boxes rounded OUTWARD to f16, pre-order (an inner node's first child is the next node)
-//   [hybrid layout: n_hyb_top + n_hyb_main entries] the same 16-byte nodes split into the tree's upper part (`top`, copied into LDS by every
-//       workgroup) and the rest (`main`), links are cursors (kHybMainBit | index into main, or index into top), portals at the crossings
-//       (scene_host.cpp build_hybrid)
 struct SceneLayout {
     uint32_t n_nodes;           // reference tree (2N-1)
     uint32_t n_cull_nodes;      // culling tree
-    uint32_t n_hyb_top;         // hybrid layout (below): entries of the part kept in LDS, portals included; 0 = the scene has none
+    uint32_t reserved0;         // (rounds 1-4: n_top_nodes)
     uint32_t n_spheres, n_quads, n_materials;
     uint32_t off_sphere, off_quad, off_material;                  // in 16-byte elements (culling nodes start at 0)
     uint32_t off_sphere_mat, off_material_kind;                   // in 4-byte elements from blob start
@@ -90,7 +81,6 @@ struct SceneLayout {
     uint32_t off_leaf_list;     // in 16-byte elements: the leaves alone, node format, skip = successor (cold part of the blob)
     uint32_t flat_walk;         // 1: few enough leaves that the streamed kernel steps the leaf list in lock-step (rt_path.h walk_flat)
     uint32_t off_compact;       // in 16-byte elements: the culling tree as 16-byte nodes (f16 boxes rounded outward), pre-order; 0 = absent
-    uint32_t n_hyb_main, off_hyb_top, off_hyb_main;   // hybrid layout: entries of the part in global memory; both arrays' offsets in 16-byte elements
     uint32_t lazy_color;        // 1: every scattering material's albedo has |component| <= 1 (so a path's attenuation stays finite and
                                 //    `color += attenuation * 0` leaves colour at +0 until the path ends): kernels need not carry the colour
 };

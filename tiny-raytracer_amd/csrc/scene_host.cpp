@@ -326,113 +326,12 @@ void dump_tree(NodeDump& d, const std::vector<Box>& boxes, const std::vector<int
 
 }  // namespace
 
-// ------------------------------------------------------------------------------------------------------------------
-// The culling tree split for the top-in-LDS walk (rt_path.h walk_hybrid; scene.h "hybrid layout"): 16-byte nodes like the compact tree,
-// in TWO arrays - `top`, the tree's most-visited upper part (an ancestor-closed set grown greedily by subtree size until `budget`
-// entries are used), which every workgroup copies into LDS, and `main`, everything below it, read from global memory.  One cursor walks
-// both: bit 30 (kHybMainBit) set = index into `main`, clear = index into `top`; a node's successor when its box passes (or it is a
-// leaf) is cursor + 1 in either array, its link is a CURSOR VALUE (so a skip link may cross from `main` back into `top`), and the
-// crossing points are ordinary nodes with a box no ray can pass:
-//   * behind every CUT node of `top` (an inner node whose children live in `main`) sits a portal whose link is the main cursor of the
-//     cut node's first child: box passes -> cursor + 1 = portal -> never passes -> cursor = link;  box fails -> the cut node's own link
-//     skips the portal;
-//   * behind the last descendant of a cut node in `main` sits a portal whose link is the top cursor the cut node's skip leads to: where
-//     a LEAF's implicit successor (cursor + 1) would have left the subtree.  Skip links that leave the subtree go there directly.
-// The walk is over when the cursor equals `n_top` (the root's skip).  Same nodes, same order, same boxes as the compact tree: the
-// portals add steps (one per subtree entered, at most one per subtree left), never a leaf.
-// ------------------------------------------------------------------------------------------------------------------
-struct HybridLayout {
-    std::vector<uint32_t> top, main;                 // 4 words per entry: (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, link)
-};
-constexpr uint32_t kHybMainBitHost = 0x40000000u, kHybLeafBitHost = 0x80000000u;
-
-void build_hybrid(const CullBuilder& cb, uint32_t budget, HybridLayout& out) {
-    const uint32_t nc = (uint32_t)cb.node_box.size();
-    auto is_leaf = [&](uint32_t i) { return cb.node_leaf[i] >= 0; };
-    auto for_children = [&](uint32_t i, auto&& fn) { for (uint32_t c = i + 1; c < (uint32_t)cb.node_skip[i]; c = (uint32_t)cb.node_skip[c]) fn(c); };
-    // 1. which inner nodes are EXPANDED (their children are in `top` too): greedily the largest subtree first while the entries fit.
-    //    Entries: one per node of `top` + one portal per cut node (inner, in `top`, not expanded).
-    std::vector<uint8_t> expanded(nc, 0);
-    uint32_t entries = 1u + (is_leaf(0) ? 0u : 1u);
-    std::vector<std::pair<uint32_t, uint32_t>> heap;                      // (subtree size, node): max-heap of cut nodes
-    if (!is_leaf(0)) heap.emplace_back((uint32_t)cb.node_skip[0], 0u);
-    while (!heap.empty()) {
-        std::pop_heap(heap.begin(), heap.end());
-        const uint32_t i = heap.back().second;
-        heap.pop_back();
-        uint32_t add = 0;
-        for_children(i, [&](uint32_t c) { add += is_leaf(c) ? 1u : 2u; });
-        if (entries - 1u + add > budget) continue;                          // does not fit: stays a cut node (smaller ones may still fit)
-        entries = entries - 1u + add;
-        expanded[i] = 1;
-        for_children(i, [&](uint32_t c) { if (!is_leaf(c)) { heap.emplace_back((uint32_t)cb.node_skip[c] - c, c); std::push_heap(heap.begin(), heap.end()); } });
-    }
-    // 2. positions.  `top` in pre-order of the truncated tree, a portal behind every cut node; `main`: per cut node (in top order) its
-    //    descendants in pre-order, then a portal.
-    std::vector<uint32_t> tpos(nc + 1, 0xFFFFFFFFu), mpos(nc, 0xFFFFFFFFu);
-    std::vector<uint32_t> top_nodes, cut_nodes;
-    {
-        std::vector<uint32_t> stack{0u};
-        uint32_t t = 0;
-        while (!stack.empty()) {                                            // explicit pre-order over the expanded part
-            const uint32_t i = stack.back();
-            stack.pop_back();
-            tpos[i] = t++;
-            top_nodes.push_back(i);
-            if (is_leaf(i)) continue;
-            if (!expanded[i]) { cut_nodes.push_back(i); t++; continue; }    // + its portal
-            std::vector<uint32_t> kids;
-            for_children(i, [&](uint32_t c) { kids.push_back(c); });
-            for (size_t k = kids.size(); k-- > 0;) stack.push_back(kids[k]);
-        }
-        tpos[nc] = t;                                                       // the end of the walk
-    }
-    const uint32_t n_top = tpos[nc];
-    uint32_t m = 0;
-    std::vector<uint32_t> portal_out(nc, 0);
-    for (uint32_t c : cut_nodes) {
-        for (uint32_t j = c + 1; j < (uint32_t)cb.node_skip[c]; j++) mpos[j] = m++;
-        portal_out[c] = m++;
-    }
-    const uint32_t n_main = m;
-    // 3. entries
-    auto box_words = [&](const Box& bx, uint32_t* w) {
-        const uint32_t lx = f32_to_f16_dir(bx.lo.x, false), ly = f32_to_f16_dir(bx.lo.y, false), lz = f32_to_f16_dir(bx.lo.z, false);
-        const uint32_t hx = f32_to_f16_dir(bx.hi.x, true), hy = f32_to_f16_dir(bx.hi.y, true), hz = f32_to_f16_dir(bx.hi.z, true);
-        w[0] = lx | ly << 16; w[1] = lz | hx << 16; w[2] = hy | hz << 16;
-    };
-    // a box no finite ray passes: x in [+inf, +inf] - both plane distances are the same infinity, so the interval is empty whatever 1/d
-    auto portal_words = [&](uint32_t* w, uint32_t link) { w[0] = 0x7C00u; w[1] = 0x7C00u << 16; w[2] = 0u; w[3] = link; };
-    out.top.assign(4u * (size_t)n_top, 0u);
-    out.main.assign(4u * (size_t)n_main, 0u);
-    // cursor of culling node `j` as seen from inside cut subtree `c` (or from `top` when c == nc)
-    for (uint32_t i : top_nodes) {
-        uint32_t* w = &out.top[4u * (size_t)tpos[i]];
-        box_words(cb.node_box[i], w);
-        if (is_leaf(i)) { w[3] = kHybLeafBitHost | (uint32_t)cb.node_leaf[i]; continue; }
-        w[3] = tpos[(uint32_t)cb.node_skip[i]];                              // the skip target of a node of `top` is in `top` (or the end)
-        if (!expanded[i]) portal_words(w + 4, kHybMainBitHost | mpos[i + 1]);     // cut node: its first child starts its part of `main`
-    }
-    for (uint32_t c : cut_nodes) {
-        const uint32_t end = (uint32_t)cb.node_skip[c];
-        const uint32_t back = tpos[end];                                     // where the walk goes on in `top` once this subtree is done
-        for (uint32_t j = c + 1; j < end; j++) {
-            uint32_t* w = &out.main[4u * (size_t)mpos[j]];
-            box_words(cb.node_box[j], w);
-            if (is_leaf(j)) { w[3] = kHybLeafBitHost | (uint32_t)cb.node_leaf[j]; continue; }
-            const uint32_t sk = (uint32_t)cb.node_skip[j];
-            w[3] = sk < end ? (kHybMainBitHost | mpos[sk]) : back;
-        }
-        portal_words(&out.main[4u * (size_t)portal_out[c]], back);
-    }
-}
-
 trt_scene_options scene_options_builtin() {
     trt_scene_options o{};
     o.cull_prune = 0.5f;
     o.flat_walk = -1;
     o.compact_nodes = -1;
-    o.top_nodes = kHybridTopDefault;
+    o.top_nodes = 0;                               // ignored since ABI 4
     o.scratch_cap_bytes = (uint64_t)32 << 30;      // one full-size streamed workspace is up to 16 GB: the cap must hold it, or every render re-allocates
     return o;
 }
@@ -521,23 +420,11 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
         L.off_compact = L.blob_bytes / 16u;
         L.blob_bytes += 16u * nc;
     }
-    // the same tree split for the top-in-LDS walk (scenes walked from global memory with 16-byte nodes; trt_scene_options.top_nodes entries)
-    HybridLayout hyb;
-    L.n_hyb_top = L.n_hyb_main = L.off_hyb_top = L.off_hyb_main = 0u;
-    uint32_t hyb_budget = opt.top_nodes > kHybridTopMax ? kHybridTopMax : opt.top_nodes;
-    if (want_compact && hyb_budget >= 4u && nc >= 2u && nc < (1u << 28)) {
-        build_hybrid(cb, hyb_budget, hyb);
-        L.n_hyb_top = (uint32_t)(hyb.top.size() / 4u);
-        L.n_hyb_main = (uint32_t)(hyb.main.size() / 4u);
-        L.off_hyb_top = L.blob_bytes / 16u;
-        L.off_hyb_main = L.off_hyb_top + L.n_hyb_top;
-        L.blob_bytes += 16u * (L.n_hyb_top + L.n_hyb_main);
-    }
     {   // every offset and size of the layout is 32 bits wide: refuse scenes that do not fit instead of wrapping around
         const uint64_t prims = (uint64_t)ns + 5ull * nq + nm;
         const uint64_t total = 16ull * (2ull * nc + prims) + 4ull * ((uint64_t)ns + nm) + 16ull                 // hot part
                                + 32ull * nn + 32ull * ((uint64_t)L.n_leaves + kLeafListPad)                          // reference tree, leaf list
-                               + (want_compact ? 16ull * nc : 0ull) + 16ull * ((uint64_t)L.n_hyb_top + L.n_hyb_main);
+                               + (want_compact ? 16ull * nc : 0ull);
         if (total > 0xFFFFFFFFull) { msg = "scene too large: the packed scene would exceed 4 GiB"; return false; }
     }
     L.all_finite = all_finite ? 1u : 0u;
@@ -576,9 +463,10 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
             dst[2 * o + 1] = F4{bx.hi.y, bx.hi.z, bitsf(at(skip[i])), bitsf(link)};
         }
     };
-    std::vector<uint32_t> cull_place(nc), ref_place(nn);
+    std::vector<uint32_t> cull_place(nc), ref_place(nn);                  // both trees are packed in pre-order
     for (uint32_t i = 0; i < nc; i++) cull_place[i] = i;
     for (uint32_t i = 0; i < nn; i++) ref_place[i] = i;
+    L.reserved0 = 0u;
     pack_nodes(f4, cb.node_box, cull_prim_geo, cb.node_skip, cull_place);
     pack_nodes(f4 + L.off_ref_nodes, b.node_box, b.node_prim, b.node_skip, ref_place);
     {   // leaf list: the leaves alone, in walk order
@@ -611,10 +499,6 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
             c[4 * i + 2] = hy | hz << 16;
             c[4 * i + 3] = cb.node_leaf[i] >= 0 ? (0x80000000u | (uint32_t)cb.node_leaf[i]) : (uint32_t)cb.node_skip[i];
         }
-    }
-    if (L.n_hyb_top) {
-        memcpy(u32 + 4u * (size_t)L.off_hyb_top, hyb.top.data(), hyb.top.size() * 4u);
-        if (!hyb.main.empty()) memcpy(u32 + 4u * (size_t)L.off_hyb_main, hyb.main.data(), hyb.main.size() * 4u);
     }
     dump_tree(out.reference, b.node_box, b.node_prim, b.node_skip);
     dump_tree(out.culling, cb.node_box, cull_prim_geo, cb.node_skip);

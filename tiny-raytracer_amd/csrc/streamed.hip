@@ -39,7 +39,6 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                                                                              uint32_t tiles_x, uint32_t n_tiles, uint32_t n_batches, uint32_t batch_spp,
                                                                              const float4* __restrict__ leaf_list,
                                                                              const uint4* __restrict__ nodes16) {
-    static_assert(WALK != WALK_HYBRID, "the top-in-LDS walk runs in the pool kernel only");
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
     const uint32_t lane = threadIdx.x & 63u;
@@ -64,7 +63,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
     Counters<STATS> ctr;
     // resumable walks (rt_path.h walk_compact, walk_fast_lds): a round's walk phase ends once only a few lanes still walk; they carry
     // their walk into the next round (100 k spheres: 324 trips per round for 222 box steps per ray, +10 %; random-spheres: see DESIGN 13)
-    constexpr bool kResumable = !STATS && (WALK == WALK_COMPACT || WALK == WALK_LDS_STACK || WALK == WALK_HYBRID);
+    constexpr bool kResumable = !STATS && (WALK == WALK_COMPACT || WALK == WALK_LDS_STACK);
     bool walking = false;                                                         // this lane's walk is parked in its leaf stack (kResumable only)
 
     TRT_CLK_START(ctr);
@@ -129,7 +128,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
                 Trav tr = trav_begin(sc, p.ray, false);                              // every lane: a new walk, or the frame of a parked one
                 if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered, ra.top_burst);
+                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
                 if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
                         radiance_store(colors, out_idx, p.color);
@@ -174,19 +173,10 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                                                                            const uint4* __restrict__ nodes16) {
     stage_scene_to_lds<MODE>(scd);
     const SceneAcc<MODE> sc{scd.blob, scd.L};
-    uint32_t lds_front = sc.lds_bytes();                                               // what sits in front of the leaf stacks in dynamic LDS
-    if constexpr (WALK == WALK_HYBRID) {
-        // top-in-LDS walk (rt_path.h walk_hybrid): the upper part of the 16-byte culling tree, copied once per workgroup
-        static_assert(MODE == MODE_GLOBAL, "the top-in-LDS walk is for scenes read from global memory");
-        const float4* __restrict__ top = scd.blob + scd.L.off_hyb_top;
-        for (uint32_t k = threadIdx.x; k < scd.L.n_hyb_top; k += blockDim.x) g_lds[k] = top[k];
-        __syncthreads();
-        lds_front = 16u * scd.L.n_hyb_top;
-    }
     const uint32_t lane = threadIdx.x & 63u;
     const V3 background = v3(ra.background[0], ra.background[1], ra.background[2]);
     const uint32_t n_spp = ra.sample_end - ra.sample_begin;
-    char* const lds_tail = reinterpret_cast<char*>(g_lds) + ((lds_front + 15u) & ~15u);
+    char* const lds_tail = reinterpret_cast<char*>(g_lds) + ((sc.lds_bytes() + 15u) & ~15u);
     float2* const leaf_stack = reinterpret_cast<float2*>(lds_tail) + (threadIdx.x >> 6) * (64u * ra.leaf_slots) + lane;
     // the pool: field f of entry e at pool[f * 64 + e]
     uint32_t* const pool = reinterpret_cast<uint32_t*>(lds_tail + (size_t)THREADS * ra.leaf_slots * sizeof(float2)) + (threadIdx.x >> 6) * (64u * kPoolDwords);
@@ -203,7 +193,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
     Counters<STATS> ctr;
     // resumable walks (rt_path.h walk_compact, walk_fast_lds): a round's walk phase ends once only a few lanes still walk; they carry
     // their walk into the next round (100 k spheres: 324 trips per round for 222 box steps per ray, +10 %; random-spheres: see DESIGN 13)
-    constexpr bool kResumable = !STATS && (WALK == WALK_COMPACT || WALK == WALK_LDS_STACK || WALK == WALK_HYBRID);
+    constexpr bool kResumable = !STATS && (WALK == WALK_COMPACT || WALK == WALK_LDS_STACK);
     bool walking = false;                                                         // this lane's walk is parked in its leaf stack (kResumable only)
 
     TRT_CLK_START(ctr);
@@ -275,7 +265,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
                 Trav tr = trav_begin(sc, p.ray, false);                              // see stream_sample_kernel
                 if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
-                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered, ra.top_burst);
+                walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
                 if (!walking) {
                     if (shade_hit<MODE, STATS, LAZY>(sc, p, tr.prim_best, tr.t_best, background, ctr)) {
                         radiance_store(colors, out_idx, p.color);
@@ -517,9 +507,6 @@ const KernelEntry kSpecialised[] = {
     TRT_SAMPLE(MODE_LDS, false, 6, 512, WALK_REGS, true),
     TRT_SAMPLE(MODE_LDS, false, 6, 768, WALK_LDS_STACK, true),
     TRT_POOL(MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true),
-    TRT_POOL(MODE_GLOBAL, false, 8, 256, WALK_HYBRID, true),     // top-in-LDS walk: up to 320 entries of the tree's upper part per workgroup,
-    TRT_POOL(MODE_GLOBAL, false, 8, 512, WALK_HYBRID, true),     //   640,
-    TRT_POOL(MODE_GLOBAL, false, 8, 1024, WALK_HYBRID, true),    //   1280 (the CU's 160 KB hold the workgroups' copies, leaf stacks and ray pools)
     TRT_DUAL(4), TRT_DUAL(5), TRT_DUAL(6), TRT_DUAL(7), TRT_DUAL(8),
 };
 // every other knob combination and the counting variants: runtime choice of the walk
@@ -555,7 +542,7 @@ const KernelEntry* find_general(int mode, int threads, int minw, bool pool, bool
 // every scene size and every knob (tests/test_host_boundary.py).
 StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra_all, const trt_tuning& tn, bool stats) {
     StreamLaunchPlan pl{};
-    size_t scene_bytes = scene_lds_bytes(L);          // what sits in front of the leaf stacks: the scene copy, or the top-in-LDS walk's part of the tree
+    const size_t scene_bytes = scene_lds_bytes(L);
     const int mode = scene_mode(L);
     // waves per SIMD / lanes per workgroup: 256-lane workgroups for small LDS copies; a big LDS copy (> 20 KB) is shared by
     // more waves: 768 lanes (12 waves, two workgroups per CU = 6 waves per SIMD) if the copy and a 4-slot LDS leaf stack
@@ -576,27 +563,12 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     if (w > 8) w = 8;
     if (threads == 512 && w > 6) w = 6;
     if (threads == 768) w = 6;
-    // top-in-LDS walk (rt_path.h walk_hybrid) of a scene that carries the split tree (trt_scene_options.top_nodes): 8 waves per SIMD, and the
-    // smallest workgroup (256 / 512 / 1024 lanes: fewer, larger workgroups = fewer LDS copies per CU) whose copy of the tree's upper part,
-    // three-slot leaf stacks and ray pool fit the CU's 160 KB at full residency
-    bool hybrid = mode == MODE_GLOBAL && L.n_hyb_top > 0u && L.off_compact != 0u && tn.no_top_cache == 0u && tn.dual_walk == 0u && !stats && !ra_all.ref_tree &&
-                  L.lazy_color && tn.runtime_walk == 0u && tn.ray_pool != 0u && ra_all.lds_leaf_stack != 0u && w == 8;
-    if (hybrid) {
-        const uint32_t hs = ra_all.leaf_slots == 0u ? 3u : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
-        int th = 0;
-        for (int t : {256, 512, 1024}) {
-            const size_t per_wg = 16u * (size_t)L.n_hyb_top + (size_t)t * hs * sizeof(float2) + (size_t)t * kPoolDwords * sizeof(uint32_t);
-            if (per_wg * (size_t)(8 * 256 / t) <= kLdsPerCu) { th = t; break; }
-        }
-        if (th == 0) hybrid = false; else threads = th;
-    }
-    if (hybrid) scene_bytes = 16u * (size_t)L.n_hyb_top;
     uint32_t wg_per_cu = (uint32_t)(w * 4 * 64 / threads);
     // slots of the LDS stack: 4 for tree walks (5 in the 768-lane plan if they fit: random-spheres +3 %, profiles/r03_defaults_sweep.txt);
     // 7 for the lock-step leaf list, whose t_best stays stale for a whole walk (Cornell 34.0 Gray/s at 4, 35.1 at 6..12) and which
     // steps two leaves per trip, so a lane must have two free
     const bool flat = L.flat_walk && !ra_all.ref_tree;
-    uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 7u : hybrid ? 3u : (threads == 768 ? 5u : 4u)) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
+    uint32_t slots = ra_all.leaf_slots == 0u ? (flat ? 7u : (threads == 768 ? 5u : 4u)) : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots);
     if (flat && slots < 2u) slots = 2u;                                         // walk_flat pushes up to two leaves per trip
     if (flat && ra_all.leaf_slots == 0u && mode == MODE_LDS && threads == 256) {
         // the default depth gives way to occupancy: the deepest stack (<= 7, >= 4) with which stack + ray pool + scene copy of
@@ -624,16 +596,12 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack and 256-lane workgroups (LDS scenes at 6
     // waves per SIMD and more, global-memory scenes at 8), and must not cost a resident workgroup either
     const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-    bool pool = lds_stack && (threads == 256 || hybrid) && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && (w == 8 || tn.dual_walk != 0u)));
+    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && (w == 8 || tn.dual_walk != 0u)));
     pool = pool && tn.ray_pool != 0u;
     if (pool) pool = (uint32_t)(kLdsPerCu / (with_stack + pool_bytes)) >= wg_per_cu;
 
     // ---- the kernel instantiation ----
-    if (hybrid && !(compact && pool)) {                // cannot happen (the sizes were checked above); never launch a plan that does not add up
-        StreamLaunchPlan none{};
-        return none;
-    }
-    const int walk = hybrid ? WALK_HYBRID : compact ? WALK_COMPACT : (flat && lds_stack) ? WALK_FLAT : lds_stack ? WALK_LDS_STACK : WALK_REGS;
+    const int walk = compact ? WALK_COMPACT : (flat && lds_stack) ? WALK_FLAT : lds_stack ? WALK_LDS_STACK : WALK_REGS;
     const bool slots_ok = lds_stack || ra_all.leaf_slots == 0u || ra_all.leaf_slots >= 4u;      // WALK_REGS has 4 register slots
     const bool specialise = !stats && slots_ok && L.lazy_color && tn.runtime_walk == 0u;
     // two paths per lane (stream_dual_kernel): scenes in global memory on 16-byte nodes with the ray pool; two leaf stacks per lane, as deep
@@ -678,7 +646,7 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     const size_t lds_bytes = lds_stack ? align16(scene_bytes) + (dual ? stack_total : stack_bytes) + (pool ? pool_bytes : 0u) : scene_bytes;
     if (lds_bytes) { const uint32_t by_lds = (uint32_t)(kLdsPerCu / lds_bytes); if (by_lds < wg_per_cu) wg_per_cu = by_lds ? by_lds : 1u; }
     pl.mode = mode; pl.threads = threads; pl.waves_per_simd = w; pl.wg_per_cu = wg_per_cu; pl.slots = slots;
-    pl.lds_stack = lds_stack; pl.flat = flat && lds_stack; pl.compact = compact; pl.pool = pool; pl.walk = walk; pl.dual = dual; pl.hybrid = hybrid;
+    pl.lds_stack = lds_stack; pl.flat = flat && lds_stack; pl.compact = compact; pl.pool = pool; pl.walk = walk; pl.dual = dual;
     pl.lds_bytes = lds_bytes; pl.scene_lds_bytes = scene_bytes;
     pl.kernel = k ? k->fn : nullptr;
     pl.kernel_minw = k ? k->minw : 0; pl.kernel_threads = k ? k->threads : 0; pl.kernel_walk = k ? k->walk : 0; pl.kernel_pool = k ? k->pool : false;
@@ -720,9 +688,7 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
     SceneDev scd = sc;
     CameraDev camd = cam;
     const float4* leaf_list = (pl.flat || pl.compact) ? sc.blob + sc.L.off_leaf_list : nullptr;
-    // 16-byte nodes: the whole culling tree, or - top-in-LDS walk - the part of it below what the workgroups keep in LDS
-    const uint4* nodes16 = pl.hybrid ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_hyb_main)
-                                     : pl.compact ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_compact) : nullptr;
+    const uint4* nodes16 = pl.compact ? reinterpret_cast<const uint4*>(sc.blob + sc.L.off_compact) : nullptr;
     const int walk_of_plan = pl.walk;
     const uint32_t resident = (uint32_t)cus * pl.wg_per_cu;
     const uint32_t waves_per_wg = (uint32_t)pl.threads / 64u;
@@ -738,7 +704,6 @@ hipError_t launch_streamed(const SceneDev& sc, const CameraDev& cam, const Rende
         if (walk_of_plan == WALK_LDS_STACK) {                                   // the LDS tree walk's own straggler threshold
             ra.stragglers = tn.lds_stragglers;
         }
-        ra.top_burst = tn.top_burst ? (tn.top_burst > 64u ? 64u : tn.top_burst) : 4u;      // top-in-LDS walk: steps out of LDS per global round
         if (!pl.lds_stack || pl.slots < 2u) ra.stragglers = 0u;                 // a parked walk occupies two slots of the lane's LDS leaf stack (rt_path.h trav_park)
         ra.sample_begin = s0;
         ra.sample_end = s0 + chunk < ra_all.sample_end ? s0 + chunk : ra_all.sample_end;
