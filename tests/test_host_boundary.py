@@ -237,9 +237,15 @@ def test_compact_nodes_are_the_culling_tree_rounded_outward(trt):
     lo32, hi32 = box[:, :3], box[:, 3:]
     lo, hi = lo16.astype(np.float32), hi16.astype(np.float32)
     assert (lo <= lo32).all() and (hi >= hi32).all()
-    # tightest: one f16 step inwards would cut into the exact box
-    assert (np.nextafter(lo16, np.float16(np.inf)).astype(np.float32) > lo32).all()
-    assert (np.nextafter(hi16, np.float16(-np.inf)).astype(np.float32) < hi32).all()
+    # round 5: the boxes are first grown by eps = 2^-19 B per axis (B = the tree's largest |coordinate| on the axis) - the slack the fused slab
+    # arithmetic of the hand-written walk needs (rt_path.h box_loop_compact) - and THEN rounded outward to the nearest f16
+    B = np.maximum(np.abs(lo32[0]), np.abs(hi32[0])).astype(np.float32)
+    eps = (B * np.float32(2.0 ** -19)).astype(np.float32)
+    lo_grown, hi_grown = (lo32 - eps).astype(np.float32), (hi32 + eps).astype(np.float32)
+    assert (lo <= lo_grown).all() and (hi >= hi_grown).all()
+    # tightest: one f16 step inwards would cut into the grown box
+    assert (np.nextafter(lo16, np.float16(np.inf)).astype(np.float32) > lo_grown).all()
+    assert (np.nextafter(hi16, np.float16(-np.inf)).astype(np.float32) < hi_grown).all()
     leaf = prim >= 0
     assert ((link & 0x80000000) != 0).tolist() == leaf.tolist()
     assert np.array_equal(link[~leaf], skip[~leaf].astype(np.uint32))
@@ -247,6 +253,53 @@ def test_compact_nodes_are_the_culling_tree_rounded_outward(trt):
     # a scene that fits LDS has no such array
     small, _ = trt.world_from_description(trt.scenes.cornell())
     assert small.get_bvh().compact_nodes() is None
+
+
+def test_fused_slab_arithmetic_on_the_grown_f16_boxes_is_conservative(trt):
+    """rt_path.h box_loop_compact (round 5) evaluates a plane's distance as fma(x, 1/d, -fl(o / d)) on the 16-byte nodes instead of the reference's
+    fl(fl(x - o) * 1/d).  Replayed on the host - the fused form in extended precision rounded once, the reference's form in float32 step by step - for
+    random rays from inside the domain (|o| <= 4 B per axis, its very edge included) against EVERY node: whenever the reference's slab test passes on a
+    node's exact f32 box (aabb.rs:36-61 with t in [0.001, t_best)), the fused test passes on its grown f16 box, and its interval starts no later."""
+    desc = trt.scenes.sphere_grid(3000, 64, 36)
+    sc = trt.world_from_description(desc)[0].get_bvh()
+    lo16, hi16, _ = sc.compact_nodes()
+    box, _, _ = sc.cull_nodes()
+    lo32, hi32 = box[:, :3].astype(np.float32), box[:, 3:].astype(np.float32)
+    lo_c, hi_c = lo16.astype(np.float32), hi16.astype(np.float32)
+    B = np.maximum(np.abs(lo32[0]), np.abs(hi32[0])).astype(np.float32)
+    rng = np.random.default_rng(5)
+    f32, ld = np.float32, np.longdouble
+    checked = passed = 0
+    for r in range(300):
+        if r % 4 == 0:                                                            # on the domain's edge, in a corner of it
+            o = (rng.choice([-4.0, 4.0], 3) * B).astype(f32)
+        elif r % 4 == 1:                                                          # anywhere in the domain
+            o = (rng.uniform(-4.0, 4.0, 3) * B).astype(f32)
+        else:                                                                     # where the rays of a render start: among the spheres
+            o = np.array([rng.uniform(-30, 30), rng.uniform(0.0, 0.5), rng.uniform(-30, 30)], f32)
+        d = rng.normal(size=3)
+        d = (d / np.linalg.norm(d)).astype(f32)
+        d[np.abs(d) < 1e-6] = f32(1e-6)
+        inv = (f32(1.0) / d).astype(f32)
+        t_best = f32(np.inf) if r % 3 == 0 else f32(rng.uniform(0.5, 3000.0))
+        with np.errstate(over="ignore", invalid="ignore"):
+            # the reference on the exact box, float32 step by step
+            a, b = ((lo32 - o).astype(f32) * inv).astype(f32), ((hi32 - o).astype(f32) * inv).astype(f32)
+            start = np.maximum(np.minimum(a, b).max(axis=1), f32(0.001))
+            end = np.minimum(np.maximum(a, b).min(axis=1), t_best)
+            ref_pass = ~(end <= start)
+            # the fused form on the grown f16 box: m = fl(o * inv); g = fl(x * inv - m), one rounding
+            m = (o * inv).astype(f32)
+            ga = (lo_c.astype(ld) * inv.astype(ld) - m.astype(ld)).astype(f32)
+            gb = (hi_c.astype(ld) * inv.astype(ld) - m.astype(ld)).astype(f32)
+            cstart = np.maximum(np.minimum(ga, gb).max(axis=1), f32(0.001))
+            cend = np.minimum(np.maximum(ga, gb).min(axis=1), t_best)
+            coarse_pass = ~(cend <= cstart)
+        assert not (ref_pass & ~coarse_pass).any(), (r, o, d)
+        assert (cstart[ref_pass] <= start[ref_pass]).all(), (r, o, d)
+        checked += len(ref_pass)
+        passed += int(ref_pass.sum())
+    assert checked > 1e6 and passed > 1000
 
 
 def test_f16_outward_rounding_handles_the_edges(trt):
@@ -266,9 +319,11 @@ def test_f16_outward_rounding_handles_the_edges(trt):
     assert (lo <= box[:, :3]).all() and (hi >= box[:, 3:]).all()
     assert np.isinf(hi).any() and np.isinf(lo).any()                             # beyond 65504: the conservative infinity
     fin = np.isfinite(lo) & np.isfinite(hi)
+    B = np.maximum(np.abs(box[0, :3]), np.abs(box[0, 3:])).astype(np.float32)
+    eps = (B * np.float32(2.0 ** -19)).astype(np.float32)                        # the slack of the fused slab arithmetic (0.19 here: B = 1e5)
     with np.errstate(over="ignore"):
-        assert (np.nextafter(lo16, np.float16(np.inf)).astype(np.float32)[fin] > box[:, :3][fin]).all()
-        assert (np.nextafter(hi16, np.float16(-np.inf)).astype(np.float32)[fin] < box[:, 3:][fin]).all()
+        assert (np.nextafter(lo16, np.float16(np.inf)).astype(np.float32)[fin] > (box[:, :3] - eps).astype(np.float32)[fin]).all()
+        assert (np.nextafter(hi16, np.float16(-np.inf)).astype(np.float32)[fin] < (box[:, 3:] + eps).astype(np.float32)[fin]).all()
 
 
 def test_header_is_valid_c_and_the_c_example_fails_loudly_without_gpu(trt, tmp_path):

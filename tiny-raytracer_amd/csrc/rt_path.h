@@ -117,12 +117,20 @@ struct Trav {
 // ref_tree: walk the reference tree whatever the ray (counting kernels: their counters then equal the oracle's).
 // A ray whose slab arithmetic can produce NaN (zero / non-finite direction component, non-finite origin) always
 // walks the reference tree with the reference's compare-and-assign slab test.
-template <int MODE>
+// COMPACT_DOMAIN (kernels whose walk is walk_compact with the hand-written loop): the fast path also needs the ray inside the domain in which that
+// loop's fused slab arithmetic is conservative - |o| <= SceneLayout::compact_origin_limit per axis and |1/d| <= 2^60 (box_loop_compact).
+template <int MODE, bool COMPACT_DOMAIN = false>
 TRT_DEV Trav trav_begin(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree) {
     Trav tr;
     tr.inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);     // (the short division of rt_device.h gains nothing here: measured)
     tr.fast = sc.L.all_finite && finite_f(tr.inv.x) && finite_f(tr.inv.y) && finite_f(tr.inv.z) && finite_f(ray.o.x) &&
               finite_f(ray.o.y) && finite_f(ray.o.z);
+    if constexpr (COMPACT_DOMAIN) {
+        const float big = 1152921504606846976.0f;                    // 2^60
+        tr.fast = tr.fast && __builtin_fabsf(ray.o.x) <= sc.L.compact_origin_limit[0] && __builtin_fabsf(ray.o.y) <= sc.L.compact_origin_limit[1] &&
+                  __builtin_fabsf(ray.o.z) <= sc.L.compact_origin_limit[2] && __builtin_fabsf(tr.inv.x) <= big && __builtin_fabsf(tr.inv.y) <= big &&
+                  __builtin_fabsf(tr.inv.z) <= big;
+    }
     tr.ref = ref_tree || !tr.fast;
     tr.n = tr.ref ? sc.L.n_nodes : sc.L.n_cull_nodes;
     tr.t_best = __builtin_inff();
@@ -588,9 +596,30 @@ TRT_DEV void walk_flat(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf
 constexpr uint32_t kCompactLeafBit = 0x80000000u;
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 
+// The exact-box re-test and the primitive test of a postponed leaf of walk_compact (its leaf_phase body).
+template <int MODE, bool STATS>
+TRT_DEV void compact_leaf_test(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf_list, const Ray& ray, Trav& tr, uint32_t leaf, Counters<STATS>& ctr) {
+    leaf &= ~kCompactLeafBit;                                        // (box_loop_compact puts the node's fourth word aside as it is)
+    const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
+    if constexpr (STATS) ctr.node++;
+    if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
+}
+
 // The box-step loop of walk_compact by hand, like box_loop_lds (same reasons, same conventions): one 16-byte node per trip through the
-// scalar-base form of global_load (a 32-bit byte offset in ONE register instead of a 64-bit address in two), 37 vector + 10 scalar
-// instructions per trip instead of 38 + 21.
+// scalar-base form of global_load (a 32-bit byte offset in ONE register instead of a 64-bit address in two).  Round 3: 37 vector + 10 scalar
+// instructions per trip instead of the compiler's 38 + 21; round 5: 28 vector.
+// FUSED SLAB ARITHMETIC (round 5).  After the NaN-ray fix this walk is bound by VALU issue (3.25 cycles per wave-instruction per SIMD against ~2.7
+// for its mix at full issue), and a third of a trip was the reference's `(x - o) * inv` on six planes: six subtractions, six multiplications.  The
+// COARSE walk need not be the reference's arithmetic - only conservative: a leaf whose coarse box passes is re-tested on its exact f32 box with
+// the reference's own slab test before its primitive is touched (walk_compact below), so a coarse test may accept too much, never too little.
+// Here a plane's distance is g = fma(x, inv, -m), m = fl(o * inv) (one v_mul per axis and call): six instructions per trip instead of twelve.
+// Error against the real number F(x) = (x - o) inv (inv the f32 value both sides use): |g - F(x)| <= u |inv| (|x| + 2.001 |o|), u = 2^-24; the
+// reference's f(x) = fl(fl(x - o) inv) on the EXACT plane x0 errs by at most 2.001 u |inv| (|x0| + |o|).  The node boxes were grown by
+// eps = 2^-19 B per axis before their outward rounding to f16 (scene_host.cpp; B = largest |coordinate| on the axis): for |o| <= 4 B that is
+// u (19.1 B) <= 2^-19 B / 1.67, more than both errors together, so for an entry plane g(x') <= f(x0) and for an exit plane g(x') >= f(x0): the
+// coarse interval contains the reference's interval on the exact box, min / max / med3 are monotonic, hence "exact box passes" implies "coarse
+// box passes" and the coarse `start` is no later than the exact one (what the leaf phase's early drop relies on).  Rays outside the domain
+// (|o| > 4 B on an axis, |inv| > 2^60) are not `fast` (trav_begin COMPACT_DOMAIN) and walk the reference tree.  Overflow: |x inv| <= 1e12 * 2^60.
 TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict__ nodes16, float2* stk, float2* limit, uint32_t n, uint32_t few) {
     const uint32_t stk_off = lds_offset(stk);
     uint32_t top = stk_off;
@@ -599,6 +628,9 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
     uint32_t cnt;
     asm volatile(
         "s_mov_b64 %[sv], exec\n"
+        "v_mul_f32_e32 v57, %[ox], %[ix]\n"                  // m = fl(o * 1/d) per axis, once per call: a plane's distance is fma(x, 1/d, -m)
+        "v_mul_f32_e32 v58, %[oy], %[iy]\n"
+        "v_mul_f32_e32 v59, %[oz], %[iz]\n"
         "1:\n"
         "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < n
         "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // top != limit
@@ -614,18 +646,12 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
         "v_cvt_f32_f16_sdwa v49, v49 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // hi.x
         "v_cvt_f32_f16_e32 v54, v50\n"                                                                    // hi.y
         "v_cvt_f32_f16_sdwa v50, v50 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // hi.z
-        "v_sub_f32_e32 v52, v52, %[ox]\n"
-        "v_sub_f32_e32 v49, v49, %[ox]\n"
-        "v_sub_f32_e32 v48, v48, %[oy]\n"
-        "v_sub_f32_e32 v54, v54, %[oy]\n"
-        "v_sub_f32_e32 v53, v53, %[oz]\n"
-        "v_sub_f32_e32 v50, v50, %[oz]\n"
-        "v_mul_f32_e32 v52, v52, %[ix]\n"
-        "v_mul_f32_e32 v49, v49, %[ix]\n"
-        "v_mul_f32_e32 v48, v48, %[iy]\n"
-        "v_mul_f32_e32 v54, v54, %[iy]\n"
-        "v_mul_f32_e32 v53, v53, %[iz]\n"
-        "v_mul_f32_e32 v50, v50, %[iz]\n"
+        "v_fma_f32 v52, v52, %[ix], -v57\n"                  // fused: ONE rounding of x / d - m instead of the reference's two of (x - o) / d;
+        "v_fma_f32 v49, v49, %[ix], -v57\n"                  //        conservative on these boxes (they were grown for it: see above the function)
+        "v_fma_f32 v48, v48, %[iy], -v58\n"
+        "v_fma_f32 v54, v54, %[iy], -v58\n"
+        "v_fma_f32 v53, v53, %[iz], -v59\n"
+        "v_fma_f32 v50, v50, %[iz], -v59\n"
         "v_med3_f32 v55, v52, v49, %[tmin]\n"                // max(t_min, entry x)   (TRT_SLAB_MED3)
         "v_med3_f32 v52, v52, v49, %[tb]\n"                  // min(t_best, exit x)
         "v_min_f32_e32 v56, v48, v54\n"
@@ -641,8 +667,7 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
         "v_cndmask_b32_e64 %[i], v51, v56, %[m1]\n"          // first child / a leaf's successor, or the skip link
         "s_and_b64 %[m1], vcc, %[m0]\n"                      // a leaf whose coarse box passes:
         "s_and_saveexec_b64 %[m0], %[m1]\n"
-        "v_and_b32_e32 v54, 0x7fffffff, v51\n"
-        "ds_write2_b32 %[top], v54, v55 offset1:1\n"         //   put (leaf sequence number, coarse start) aside
+        "ds_write2_b32 %[top], v51, v55 offset1:1\n"         //   put (LEAF | leaf sequence number, coarse start) aside (compact_leaf_test strips the bit)
         "v_add_u32_e32 %[top], 0x200, %[top]\n"
         "s_mov_b64 exec, %[m0]\n"
         "s_bcnt1_i32_b64 %[cnt], exec\n"
@@ -653,7 +678,7 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
         : [i] "+v"(tr.i), [top] "+v"(top), [sv] "=&s"(saved), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt)
         : [n] "s"(n), [few] "s"(few), [nodes] "s"(nodes16), [lim] "v"(lim), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(tr.inv.x),
           [iy] "v"(tr.inv.y), [iz] "v"(tr.inv.z), [tb] "v"(tr.t_best), [tmin] "s"(kTMin)
-        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
+        : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
     return stk + ((top - stk_off) >> 3);
 }
 
@@ -701,11 +726,7 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
         // The coarse box contains the exact one, so its interval starts no later: a leaf whose COARSE start is not below the
         // current t_best fails the exact test too and is dropped by the scan without touching memory; the others take the
         // reference's leaf-box test on the exact f32 box, at the leaf's turn.
-        if (top != stk) leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) {
-            const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
-            if constexpr (STATS) ctr.node++;
-            if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
-        });
+        if (top != stk) leaf_phase<MODE, STATS>(stk, top, tr, ctr, [&](uint32_t leaf) { compact_leaf_test<MODE, STATS>(sc, leaf_list, ray, tr, leaf, ctr); });
         TRT_CLK(ctr, 2);
         if (tr.i >= n) return true;
         if ((uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)) <= few) { trav_park(stk, tr); return false; }      // resumable: see walk_fast_lds
@@ -804,14 +825,6 @@ TRT_DEV void box_loop_compact2(uint32_t& iA, uint32_t& iB, const V3& oA, const V
         : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
     topA_out = stkA + ((topA - stkA_off) >> 3);
     topB_out = stkB + ((topB - stkB_off) >> 3);
-}
-
-// The exact-box re-test and the primitive test of a postponed leaf of walk_compact (its leaf_phase body).
-template <int MODE, bool STATS>
-TRT_DEV void compact_leaf_test(const SceneAcc<MODE>& sc, const float4* __restrict__ leaf_list, const Ray& ray, Trav& tr, uint32_t leaf, Counters<STATS>& ctr) {
-    const float4 na = leaf_list[2u * leaf], nb = leaf_list[2u * leaf + 1u];
-    if constexpr (STATS) ctr.node++;
-    if (slab_fast(na, nb, ray.o, tr.inv, kTMin, tr.t_best)) trav_leaf<MODE, STATS>(sc, ray, tr, __float_as_uint(nb.w), ctr);
 }
 
 // Both walks of a lane, resumable like walk_compact: returns with doneA / doneB = "that slot's walk is complete" once at most `few` rays

@@ -81,6 +81,7 @@ struct SceneLayout {
     uint32_t off_leaf_list;     // in 16-byte elements: the leaves alone, node format, skip = successor (cold part of the blob)
     uint32_t flat_walk;         // 1: few enough leaves that the streamed kernel steps the leaf list in lock-step (rt_path.h walk_flat)
     uint32_t off_compact;       // in 16-byte elements: the culling tree as 16-byte nodes (f16 boxes rounded outward), pre-order; 0 = absent
+    float compact_origin_limit[3];   // 16-byte nodes: |ray origin| per axis up to which walk_compact's fused slab arithmetic is conservative (0: never)
     uint32_t lazy_color;        // 1: every scattering material's albedo has |component| <= 1 (so a path's attenuation stays finite and
                                 //    `color += attenuation * 0` leaves colour at +0 until the path ends): kernels need not carry the colour
 };

@@ -483,7 +483,27 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
             dst[0] = last[0]; dst[1] = last[1];
         }
     }
+    L.compact_origin_limit[0] = L.compact_origin_limit[1] = L.compact_origin_limit[2] = 0.0f;
     if (L.off_compact) {   // compact culling tree: f16 boxes rounded outward (any superset box keeps the hits: DESIGN.md 4.1), pre-order
+        // Round 5: the hand-written walk over these nodes evaluates a plane's distance as fma(x, 1/d, -fl(o * 1/d)) - one instruction instead of the
+        // reference's fl(fl(x - o) * 1/d), two - which is NOT the reference's value: it may err by u (|x| + 2.001 |o|) |1/d|, u = 2^-24, and the
+        // reference's own value by 2.001 u (|x| + |o|) |1/d| (rt_path.h box_loop_compact has the derivation).  The boxes therefore grow by
+        // eps = 2^-19 B per axis (B = the largest |coordinate| of the tree on that axis) BEFORE they are rounded outward to f16: for ray origins with
+        // |o| <= 4 B that is 1.67 times the two errors together, so a coarse box never rejects what the reference's arithmetic on the exact box
+        // accepts.  eps is 0.002 where f16's own spacing is 0.125 (|x| in [128, 256)): the tree does not get looser in any way that shows.
+        // Rays that start further out (or whose 1/d exceeds 2^60) walk the reference tree like every ray outside the fast-slab domain.
+        float eps[3];
+        {
+            const Box& root = cb.node_box[0];
+            const float b3[3] = {fmaxf(fabsf(root.lo.x), fabsf(root.hi.x)), fmaxf(fabsf(root.lo.y), fabsf(root.hi.y)), fmaxf(fabsf(root.lo.z), fabsf(root.hi.z))};
+            for (int a = 0; a < 3; a++) {
+                const bool ok = all_finite && b3[a] <= 1.0e12f;                           // (products with 1/d <= 2^60 and 4 B stay far from overflow)
+                eps[a] = ok ? b3[a] * 1.9073486328125e-06f : 0.0f;                       // 2^-19 B
+                L.compact_origin_limit[a] = ok ? 4.0f * b3[a] : 0.0f;
+            }
+            if (!(L.compact_origin_limit[0] > 0.0f && L.compact_origin_limit[1] > 0.0f && L.compact_origin_limit[2] > 0.0f))
+                L.compact_origin_limit[0] = L.compact_origin_limit[1] = L.compact_origin_limit[2] = 0.0f;
+        }
         uint32_t* c = u32 + 4u * (size_t)L.off_compact;
         std::vector<int32_t> leaf_seq(nc, -1);
         {
@@ -492,8 +512,8 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
         }
         for (uint32_t i = 0; i < nc; i++) {
             const Box& bx = cb.node_box[i];
-            const uint32_t lx = f32_to_f16_dir(bx.lo.x, false), ly = f32_to_f16_dir(bx.lo.y, false), lz = f32_to_f16_dir(bx.lo.z, false);
-            const uint32_t hx = f32_to_f16_dir(bx.hi.x, true), hy = f32_to_f16_dir(bx.hi.y, true), hz = f32_to_f16_dir(bx.hi.z, true);
+            const uint32_t lx = f32_to_f16_dir(bx.lo.x - eps[0], false), ly = f32_to_f16_dir(bx.lo.y - eps[1], false), lz = f32_to_f16_dir(bx.lo.z - eps[2], false);
+            const uint32_t hx = f32_to_f16_dir(bx.hi.x + eps[0], true), hy = f32_to_f16_dir(bx.hi.y + eps[1], true), hz = f32_to_f16_dir(bx.hi.z + eps[2], true);
             c[4 * i + 0] = lx | ly << 16;
             c[4 * i + 1] = lz | hx << 16;
             c[4 * i + 2] = hy | hz << 16;

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_sample_kernel(SceneDev s
             if constexpr (kResumable) {
                 // per-lane tree walk: a lane whose walk is still under way when most of the wave has finished carries it into the
                 // next round (rt_path.h walk_compact) and is not shaded in this one
-                Trav tr = trav_begin(sc, p.ray, false);                              // every lane: a new walk, or the frame of a parked one
+                Trav tr = trav_begin<MODE, WALK == WALK_COMPACT>(sc, p.ray, false);                              // every lane: a new walk, or the frame of a parked one
                 if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
                 walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
         if (has_path) {
             if constexpr (STATS) { if (first_active_lane()) ctr.w_rounds++; }
             if constexpr (kResumable) {
-                Trav tr = trav_begin(sc, p.ray, false);                              // see stream_sample_kernel
+                Trav tr = trav_begin<MODE, WALK == WALK_COMPACT>(sc, p.ray, false);                              // see stream_sample_kernel
                 if (walking) trav_unpark(leaf_stack, tr); else n_rays++;
                 const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));
                 walking = !closest_hit_resume<MODE, STATS, WALK>(sc, p.ray, tr, ctr, ra.leaf_slots, leaf_stack, leaf_list, nodes16, ra.stragglers, entered);

@@ -61,8 +61,10 @@ def asm_loop_counts():
     per_box = vcount(flat_box)                                              # the slab test proper
     # box_loop_flat: + v_mov (link copy) and v_add (stack top) under the push mask per box
     flat = per_box + 2
-    lds = re.search(r"TRT_DEV float2\* box_loop_lds\(.*?asm volatile\((.*?)\n\s*:", src, re.S).group(1)
-    compact = re.search(r"TRT_DEV float2\* box_loop_compact\(.*?asm volatile\((.*?)\n\s*:", src, re.S).group(1)
+    def trip(name):                       # the loop body proper: between the labels 1: and 2: of the asm block
+        block = re.search(r"TRT_DEV float2\* " + name + r"\(.*?asm volatile\((.*?)\n\s*:", src, re.S).group(1)
+        return block[block.index('"1:'):block.index('"2:')]
+    lds, compact = trip("box_loop_lds"), trip("box_loop_compact")
     return {"box_step_flat": flat, "box_step_lds": vcount(lds), "box_step_compact": vcount(compact), "slab_test_alone": per_box}
 
 
