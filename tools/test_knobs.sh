@@ -14,7 +14,7 @@
 # the suite also runs once on that build.
 out=gpurun_out/knobs; mkdir -p $out
 [ -f build/libtinyrt_cxxloops.so ] && TRT_EXTRA_KNOBS="$TRT_EXTRA_KNOBS TRT_LIB_PATH=$PWD/build/libtinyrt_cxxloops.so"
-skip='not leaf_slots_are and not lockstep and not global_memory_walks and not full_size_schedules and not full_baseline and not cfg5 and not at_size and not full_sample_count'
+skip='not leaf_slots_are and not lockstep and not global_memory_walks and not full_size_schedules and not full_baseline and not cfg5 and not at_size and not full_sample_count and not hbm_held'
 for e in "TRT_RAY_POOL=0" "TRT_FLAT_WALK=0" "TRT_LDS_LEAF_STACK=0" "TRT_COMPACT_NODES=0" "TRT_STREAM_MINW=5" "TRT_STREAM_MINW=7" "TRT_STREAM_MINW=8" "TRT_LEAF_SLOTS=1" "TRT_LEAF_SLOTS=2" \
          "TRT_RUNTIME_WALK=1" "TRT_BIG_THREADS=512" "TRT_STRAGGLERS=0" "TRT_STRAGGLERS=40" "TRT_LDS_STRAGGLERS=0" "TRT_LDS_STRAGGLERS=24" "TRT_CULL_PRUNE=0.8" \
          "TRT_DUAL_WALK=1" "TRT_DUAL_WALK=1 TRT_STREAM_MINW=6" "TRT_DUAL_WALK=1 TRT_STREAM_MINW=4 TRT_STRAGGLERS=0" "TRT_STREAM_BATCH_SPP=3" "TRT_RADIANCE_GB=1" $TRT_EXTRA_KNOBS; do
