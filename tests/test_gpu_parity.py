@@ -121,6 +121,42 @@ def test_large_scene_traversed_from_global_memory(trt, orc):
         assert gst[k] == cst[k], k
 
 
+@pytest.mark.parametrize("case", ["camera inside", "camera on the domain's edge", "camera far outside", "a far-away sphere inflates the bound", "tiny scene coordinates"])
+def test_fused_slab_walk_in_and_out_of_its_domain(trt, orc, case):
+    """rt_path.h box_loop_compact's fused slab arithmetic (round 5) is conservative for ray origins with |o| <= 4 B per axis (B = the tree's largest
+    |coordinate| on the axis); rays that start further out walk the reference tree.  Frames and ray counts equal the oracle's on both sides of that
+    border, with the bound blown up by one far-away sphere (every box then grows by 2^-19 B = 0.19), and on a scene a thousand times smaller."""
+    desc = trt.scenes.sphere_grid(3000, 96, 54)                        # walked from global memory: 16-byte nodes
+    cam = dict(desc["camera"])
+    geos = list(desc["geometries"])
+    if case == "camera on the domain's edge":
+        cam["position"] = (3999.0, 40.0, 20.0)                         # B_x = 1000 (the ground sphere): |o.x| just inside 4 B
+        cam["focus_distance"] = 4000.0
+    elif case == "camera far outside":
+        cam["position"] = (9000.0, 800.0, 7000.0)                      # primary rays leave the domain: reference-tree walk; bounces are inside it
+        cam["focus_distance"] = 11000.0
+        cam["vertical_fov"] = 1.0
+    elif case == "a far-away sphere inflates the bound":
+        geos.append(("sphere", (1.0e5, 50.0, -3.0e4), 10.0, desc["materials"][3][0]))
+    elif case == "tiny scene coordinates":
+        k = 1.0e-3
+        geos = [(g[0], tuple(c * k for c in g[1]), g[2] * k, g[3]) for g in geos]
+        cam["position"] = tuple(c * k for c in cam["position"])
+        cam["focus_distance"] = cam["focus_distance"] * k
+    d2 = dict(desc, geometries=geos, camera=cam)
+    ow, ocam = orc.world_from_description(d2)
+    cpu, cst = orc.render(ow, ocam, 3, 50, d2["background"], seed=11, nthreads=8)
+    pw, pcam = trt.world_from_description(d2)
+    assert pw.get_bvh().info()["lds_bytes"] == 0
+    r = trt.Renderer(3, 1, 50, False, d2["background"], seed=11)
+    assert r.launch_plan(pcam, pw.get_bvh())["walk"] == 3
+    gpu = r.render(pcam, pw).data
+    assert_bit_equal(gpu, cpu, case)
+    assert r.last_stats["rays"] == cst["rays"]
+    if case != "tiny scene coordinates":
+        assert gpu.mean() > 0.05                                       # (the frame shows something)
+
+
 @pytest.mark.parametrize("wh", [(2, 2), (17, 5), (33, 47), (64, 16), (130, 3)])
 def test_ragged_image_sizes(trt, orc, wh):
     desc = trt.scenes.cornell(*wh)

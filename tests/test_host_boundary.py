@@ -465,7 +465,9 @@ def test_default_plans_of_the_three_baseline_scenes(trt):
     assert (pl["walk"], pl["threads_per_workgroup"], pl["workgroups_per_cu"], pl["ray_pool"], pl["specialised"]) == (1, 768, 2, 0, 1)
     w, cam = trt.world_from_description(trt.scenes.sphere_grid(4000, 64, 48))
     pl = _plan(trt, w.get_bvh(), cam)
-    assert (pl["scene_mode"], pl["walk"], pl["waves_per_simd"], pl["ray_pool"], pl["specialised"]) == (0, 3, 8, 1, 1)
+    assert (pl["scene_mode"], pl["walk"], pl["waves_per_simd"], pl["ray_pool"], pl["specialised"]) == (0, 3, 7, 1, 1)      # fits L2: 7 waves, no spills
+    pl = _plan(trt, w.get_bvh(), cam, tuning={"stream_waves_per_simd": 8})
+    assert (pl["walk"], pl["waves_per_simd"], pl["ray_pool"], pl["specialised"]) == (3, 8, 1, 1)
 
 
 @pytest.mark.parametrize("height", [1, 15, 16, 17, 31, 32, 33, 250, 500, 1080, 2048, 2160])

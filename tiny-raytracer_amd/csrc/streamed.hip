@@ -507,6 +507,7 @@ const KernelEntry kSpecialised[] = {
     TRT_SAMPLE(MODE_LDS, false, 6, 512, WALK_REGS, true),
     TRT_SAMPLE(MODE_LDS, false, 6, 768, WALK_LDS_STACK, true),
     TRT_POOL(MODE_GLOBAL, false, 8, 256, WALK_COMPACT, true),
+    TRT_POOL(MODE_GLOBAL, false, 7, 256, WALK_COMPACT, true),     // 72 VGPRs: nothing spilled (at 8 waves the fused slab arithmetic spills ten registers)
     TRT_DUAL(4), TRT_DUAL(5), TRT_DUAL(6), TRT_DUAL(7), TRT_DUAL(8),
 };
 // every other knob combination and the counting variants: runtime choice of the walk
@@ -557,7 +558,10 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     // LDS scenes: 6 waves per SIMD.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box
     // step once the compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6,
     // 2.29 at 8)
-    int w = mode == MODE_LDS ? 6 : 8;
+    // (round 5, without the NaN-ray tail and with the fused slab arithmetic: a tree that fits the chip's 32 MiB of L2 runs 5 % faster at 7 waves
+    // with no spilled register than at 8 with ten; a scene whose walk waits for memory - sphere_field, 1 M spheres and up - wants the eighth wave:
+    // profiles/r05_waves7_ab.txt)
+    int w = mode == MODE_LDS ? 6 : (L.hot_bytes <= (32u << 20) ? 7 : 8);
     if (tn.stream_waves_per_simd) w = (int)tn.stream_waves_per_simd;
     if (w < 5 && !(tn.dual_walk != 0u && mode == MODE_GLOBAL && w == 4)) w = 5;      // (4: the two-path kernel only - eight rays per SIMD like 8 x 1)
     if (w > 8) w = 8;
@@ -596,7 +600,7 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack and 256-lane workgroups (LDS scenes at 6
     // waves per SIMD and more, global-memory scenes at 8), and must not cost a resident workgroup either
     const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && (w == 8 || tn.dual_walk != 0u)));
+    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && (w >= 7 || tn.dual_walk != 0u)));
     pool = pool && tn.ray_pool != 0u;
     if (pool) pool = (uint32_t)(kLdsPerCu / (with_stack + pool_bytes)) >= wg_per_cu;
 
