@@ -161,7 +161,8 @@ enum trt_backend {
  * the environment; two threads may render one scene with different tunings at the same time. */
 typedef struct {
     uint32_t stream_waves_per_simd;   /* streamed backend: waves per SIMD grid and launch bound are sized for; 0 = by scene (6 for scenes
-                                         in LDS, 8 for scenes in global memory); 5..8 (4 with dual_walk on a scene in global memory)   TRT_STREAM_MINW */
+                                         in LDS, 7 for scenes in global memory that fit the 32 MiB of L2, 8 beyond); 5..8 (4 with dual_walk on a
+                                         scene in global memory)                                            TRT_STREAM_MINW */
     uint32_t stream_big_threads;      /* lanes per workgroup for LDS scene copies above 20 KB: 0 = auto, 512, 768   TRT_BIG_THREADS */
     uint32_t stream_batch_spp;        /* samples per pixel in one work batch of a wave (8)                  TRT_STREAM_BATCH_SPP */
     uint32_t radiance_gb;             /* radiance records of one streamed launch, GiB (16; 1..64)           TRT_RADIANCE_GB */
