@@ -470,6 +470,38 @@ def test_default_plans_of_the_three_baseline_scenes(trt):
     assert (pl["walk"], pl["waves_per_simd"], pl["ray_pool"], pl["specialised"]) == (3, 8, 1, 1)
 
 
+def test_bulk_sphere_add_is_the_loop_of_single_adds(trt, orc):
+    """trt_world_add_spheres (ABI 4) = `for i in 0..n { world.add_geometry(Sphere::new(..)) }` (world.rs:23-25) in array order: the compiled scene is
+    the same byte for byte as after n single adds, in the product and in the oracle; an index out of range adds nothing (all or nothing)."""
+    desc = trt.scenes.sphere_field(3000, 32, 24, palette=16)
+    cr, mat_pos = desc["bulk_spheres"]
+    names = [m[0] for m in desc["materials"]]
+    listed = dict(desc, bulk_spheres=None,
+                  geometries=list(desc["geometries"]) + [("sphere", tuple(float(v) for v in cr[i, :3]), float(cr[i, 3]), names[mat_pos[i]]) for i in range(len(cr))])
+    wb, _ = trt.world_from_description(desc)
+    wl, _ = trt.world_from_description(listed)
+    assert wb.num_geometries() == wl.num_geometries() == 3001
+    for a, b in zip(wb.get_bvh().nodes() + wb.get_bvh().cull_nodes() + wb.get_bvh().compact_nodes(), wl.get_bvh().nodes() + wl.get_bvh().cull_nodes() + wl.get_bvh().compact_nodes()):
+        assert np.array_equal(np.ascontiguousarray(a).view(np.uint8), np.ascontiguousarray(b).view(np.uint8))
+    ob, _ = orc.world_from_description(desc)
+    ol, _ = orc.world_from_description(listed)
+    for a, b in zip(ob.bvh_dump(), ol.bvh_dump()):
+        assert np.array_equal(a.view(np.uint8), b.view(np.uint8))
+    # product tree == oracle tree on the bulk scene too
+    assert np.array_equal(wb.get_bvh().nodes()[0].view(np.uint32), ob.bvh_dump()[0].view(np.uint32))
+    before = wb.num_geometries()
+    bad = np.array([0, 1, 10 ** 6], np.uint32)                               # the third index does not exist
+    with pytest.raises(trt.TinyRTError):
+        wb.add_spheres(cr[:3], bad)
+    assert wb.num_geometries() == before
+    wb.add_spheres(np.zeros((0, 4), np.float32), np.zeros(0, np.uint32))       # empty: fine
+    assert wb.num_geometries() == before
+    # the generator is a pure function of (n, seed)
+    again = trt.scenes.sphere_field(3000, 32, 24, palette=16)
+    assert np.array_equal(again["bulk_spheres"][0], cr) and np.array_equal(again["bulk_spheres"][1], mat_pos)
+    assert not np.array_equal(trt.scenes.sphere_field(3000, 32, 24, seed=45, palette=16)["bulk_spheres"][0], cr)
+
+
 @pytest.mark.parametrize("height", [1, 15, 16, 17, 31, 32, 33, 250, 500, 1080, 2048, 2160])
 @pytest.mark.parametrize("ndev", [1, 2, 3, 8, 13])
 def test_band_copy_plan_places_every_row_exactly_once(trt, height, ndev):
