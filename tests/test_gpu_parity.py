@@ -149,7 +149,8 @@ def test_fused_slab_walk_in_and_out_of_its_domain(trt, orc, case):
     pw, pcam = trt.world_from_description(d2)
     assert pw.get_bvh().info()["lds_bytes"] == 0
     r = trt.Renderer(3, 1, 50, False, d2["background"], seed=11)
-    assert r.launch_plan(pcam, pw.get_bvh())["walk"] == 3
+    if not any(k.startswith("TRT_") and k not in ("TRT_LIB_PATH",) for k in os.environ):
+        assert r.launch_plan(pcam, pw.get_bvh())["walk"] == 3             # (default tuning: the 16-byte-node walk; tools/test_knobs.sh runs this under others)
     gpu = r.render(pcam, pw).data
     assert_bit_equal(gpu, cpu, case)
     assert r.last_stats["rays"] == cst["rays"]
