@@ -282,6 +282,29 @@ def short_run(trt, torch, dev, scene_name, spheres, W, H, S, steps, warmup, dept
     rf = valu_roofline(key, avg_ms, rays / n_launch if n_launch else 0.0, warnings)
     kernel = trt.lib.trt_dominant_kernel(scene._h, C.byref(cam.pod), C.byref(renderer.params())).decode()
     info = scene.info()
+    # useful-work fraction of this scene too (main() has the definition): one untimed step of the counting kernel on the culling tree
+    useful = None
+    table, table_stale = isa_event_costs()
+    if table is not None and not table_stale and avg_ms and n_launch:
+        try:
+            uctr = torch.zeros(16, dtype=torch.int64, device=dev)
+            s0, s1, _ = step_range(warmup, S)
+            renderer.render_device(cam, scene, acc.data_ptr(), stream.cuda_stream, uctr.data_ptr(), sample_begin=s0, sample_end=s1, accumulate=0, collect_stats=2)
+            torch.cuda.synchronize()
+            names = ("samples", "rays", "node_tests", "sphere_tests", "quad_plane_tests", "quad_inside_tests", "shades")
+            uc = dict(zip(names, [int(v) for v in uctr[:7].tolist()]))
+            uc.update(zip(("shade_lambertian", "shade_metal", "shade_dielectric", "shade_light"), [int(v) for v in uctr[12:16].tolist()]))
+            walk = renderer.launch_plan(cam, scene)["walk"]
+            total, parts, box_cost = useful_lane_instructions(uc, walk, info["num_quads"], info["num_spheres"], table)
+            per_ray = total / max(uc["rays"], 1)
+            rate = per_ray * (rays / n_launch) / (avg_ms * 1e-3) / 1e12
+            useful = {"useful_frac": round(rate / (VALU_PEAK_GINST * 64.0 / 1e3), 4), "lane_instructions_per_ray": round(per_ray, 1),
+                      "box_tests_per_ray": round(uc["node_tests"] / max(uc["rays"], 1), 2), "valu_per_box_test": box_cost,
+                      "per_ray_by_event": {k: round(v / max(uc["rays"], 1), 1) for k, v in parts.items()}}
+            if rf.get("valu_wave_insts_per_ray") and rf.get("mean_active_lanes"):
+                useful["useful_over_issued"] = round(per_ray / (rf["valu_wave_insts_per_ray"] * rf["mean_active_lanes"]), 3)
+        except Exception as e:                                   # noqa: BLE001 - the bench line must still be printed
+            useful = {"error": repr(e)}
     out = {"workload": f"{scene_name}{' ' + str(spheres) + ' spheres' if spheres else ''} {W}x{H}, depth {depth}, {S} spp per step (of 4096), {backend_name}, seed 1",
            "scene": {"primitives": info["num_spheres"] + info["num_quads"], "packed_bytes": info["device_bytes"], "build_s": round(t_scene, 2)},
            "value": round(rays / elapsed / 1e6, 2),
@@ -289,7 +312,7 @@ def short_run(trt, torch, dev, scene_name, spheres, W, H, S, steps, warmup, dept
            "roofline": {"kernel": kernel, "avg_launch_ms": round(avg_ms, 4) if avg_ms else None, "launches_timed": n_launch,
                         "frac": rf["frac"], "issue_frac": rf.get("issue_frac"), "mean_active_lanes": rf.get("mean_active_lanes"),
                         "cycles_per_valu_inst_per_simd": rf.get("cycles_per_valu_inst_per_simd"), "traffic": rf.get("traffic"),
-                        "hbm": rf.get("hbm"), "pmc_key": key, "pmc_stale": rf["pmc_stale"], "warnings": warnings}}
+                        "hbm": rf.get("hbm"), "useful": useful, "pmc_key": key, "pmc_stale": rf["pmc_stale"], "warnings": warnings}}
     del acc, scene, world
     return out
 
