@@ -79,6 +79,28 @@ int main(int argc, char** argv) {
         if (a != b) { std::printf("leaf sequences differ\n"); return 1; }
         if (s.blob.size() != s.layout.blob_bytes || s.layout.hot_bytes > s.layout.blob_bytes) { std::printf("layout sizes\n"); return 1; }
     }
+    {   // a world large enough for the THREADED builders (round 5: reference-order tree from 32 768 primitives, culling tree from 65 536 leaves): the same
+        // invariants, and two builds of it - whatever the threads' interleaving - pack the same bytes
+        World big;
+        big.material_index.emplace("m", 0u);
+        big.materials.push_back(trt_material{0u, trt_vec3{0.5f, 0.5f, 0.5f}, 0.0f});
+        const int n_big = 90000;
+        for (int i = 0; i < n_big; i++) {
+            Geometry g{};
+            g.kind = i % 5 == 0 ? 1u : 0u;
+            g.a = trt_vec3{frange(-300, 300), frange(0, 3), frange(-300, 300)};
+            if (i % 97 == 0) g.a.x = std::floor(g.a.x);                           // ties on the sort key
+            if (g.kind == 0) g.b = trt_vec3{frange(0.05f, 0.5f), 0, 0};
+            else { g.b = trt_vec3{frange(-1, 1), frange(-1, 1), frange(-1, 1)}; g.c = trt_vec3{frange(-1, 1), frange(-1, 1), frange(-1, 1)}; }
+            big.geometries.push_back(g);
+        }
+        SceneHost s1, s2;
+        std::string m1;
+        if (!compile_scene(big, scene_options_builtin(), s1, m1) || !compile_scene(big, scene_options_builtin(), s2, m1)) { std::printf("big world: %s\n", m1.c_str()); return 1; }
+        if (check_tree(s1.reference, (size_t)n_big, true, "big reference")) return 1;
+        if (check_tree(s1.culling, (size_t)n_big, false, "big culling")) return 1;
+        if (s1.blob != s2.blob || s1.reference.skip != s2.reference.skip || s1.culling.skip != s2.culling.skip) { std::printf("two builds of one world differ\n"); return 1; }
+    }
     World empty;
     SceneHost s;
     std::string msg;

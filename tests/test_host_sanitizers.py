@@ -17,6 +17,17 @@ def test_scene_compiler_under_asan_ubsan(tmp_path):
     assert "ok 40 worlds" in r.stdout
 
 
+def test_scene_compiler_under_tsan(tmp_path):
+    """Round 5: the reference-order tree and the culling tree of large worlds are built on several threads (scene_host.cpp run_halves); the check's
+    90 000-primitive world takes that path.  ThreadSanitizer build, two builds of the world compared byte for byte inside the check."""
+    exe = str(tmp_path / "scene_host_check_tsan")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-ffp-contract=off", "-pthread",
+                    os.path.join(ROOT, "tests", "native", "scene_host_check.cpp"),
+                    os.path.join(ROOT, "tiny-raytracer_amd", "csrc", "scene_host.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe, "6"], capture_output=True, text=True, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and "ok 6 worlds" in r.stdout, r.stdout + r.stderr
+
+
 def test_oracle_under_asan_ubsan(tmp_path):
     """The oracle's C restatement, same sanitizers: one small multi-threaded render through a tiny C driver."""
     drv = tmp_path / "drv.c"

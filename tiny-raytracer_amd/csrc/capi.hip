@@ -691,6 +691,8 @@ int trt_scene_create_ex(const trt_world* w, const trt_scene_options* options, tr
         *out = s;
     } catch (const std::bad_alloc&) {
         return fail(TRT_ERR_OOM, "out of memory");
+    } catch (const std::exception& e) {                         // (the scene compiler builds its trees on several threads: nothing may leave the C ABI)
+        return fail(TRT_ERR_INVALID_ARG, std::string("scene compilation failed: ") + e.what());
     }
     return TRT_OK;
 }

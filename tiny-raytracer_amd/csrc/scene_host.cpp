@@ -12,6 +12,8 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <exception>
+#include <system_error>
 #include <thread>
 
 namespace trt {
@@ -63,6 +65,30 @@ inline float bitsf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
 // parent handed them over; here: one u64 per object, (order-preserving key << 32) | position in the incoming order, and a plain sort of those -
 // equal keys stay in incoming order, which is what a stable sort does, without an indirect comparison per step (round 5: 4 M spheres in
 // seconds instead of most of a minute).
+// Runs `left_half` on a new thread and `right_half` on this one.  No exception may leave a thread function (std::terminate) or this library (C ABI):
+// what the other thread throws - std::bad_alloc on a scene of millions - is carried over and rethrown here, after both halves have ended; if the
+// system has no thread to give, this thread does both halves.
+template <typename L, typename R>
+void run_halves(L&& left_half, R&& right_half) {
+    std::exception_ptr left_error;
+    std::thread t;
+    bool spawned = false;
+    try {
+        t = std::thread([&] { try { left_half(); } catch (...) { left_error = std::current_exception(); } });
+        spawned = true;
+    } catch (const std::system_error&) {
+    }
+    try {
+        if (!spawned) left_half();
+        right_half();
+    } catch (...) {
+        if (spawned) t.join();
+        throw;
+    }
+    if (spawned) t.join();
+    if (left_error) std::rethrow_exception(left_error);
+}
+
 struct Builder {
     const std::vector<Box>& prim_box;
     std::vector<Box> node_box;
@@ -119,9 +145,7 @@ struct Builder {
             const uint32_t l = me + 1, r = me + 2 * (uint32_t)mid;
             if (threads > 1 && n >= 32768) {
                 const unsigned tl = threads / 2, tr = threads - tl;
-                std::thread left([&] { build(l, objs, mid, depth + 1, tl); });
-                build(r, objs + mid, n - mid, depth + 1, tr);
-                left.join();
+                run_halves([&] { build(l, objs, mid, depth + 1, tl); }, [&] { build(r, objs + mid, n - mid, depth + 1, tr); });
             } else {
                 build(l, objs, mid, depth + 1, 1);
                 build(r, objs + mid, n - mid, depth + 1, 1);
@@ -294,9 +318,7 @@ struct CullBuilder {
         unsigned tl = (unsigned)(((uint64_t)threads * sp.k + m / 2) / m);
         if (tl < 1) tl = 1;
         if (tl >= threads) tl = threads - 1;
-        std::thread t([&] { build_parallel(a, a + sp.k, child_parent_sa, left, tl); });
-        build_parallel(a + sp.k, b, child_parent_sa, right, threads - tl);
-        t.join();
+        run_halves([&] { build_parallel(a, a + sp.k, child_parent_sa, left, tl); }, [&] { build_parallel(a + sp.k, b, child_parent_sa, right, threads - tl); });
         out.append(left);
         out.append(right);
         if (sp.emit) out.skip[(size_t)me] = (int32_t)out.box.size();
