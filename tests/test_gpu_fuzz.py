@@ -153,6 +153,20 @@ def test_short_sqrt_is_sqrtf_on_every_float_in_range(tmp_path):
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
 
 
+def test_fma_mix_is_convert_then_fma_for_every_f16(tmp_path):
+    """rt_path.h box_loop_compact (round 5) lets v_fma_mix_f32 read a node's f16 coordinate straight out of a half of its word: one instruction
+    per plane instead of a conversion and an FMA.  tools/micro/fma_mix_exact.hip compares the two forms for EVERY f16 bit pattern (subnormals
+    included - flushing them would move the planes of a millimetre-sized scene by more than their boxes' slack) in both halves of a word against
+    4096 (1/d, -m) pairs each: 5.4e8 fused operations, exits non-zero on any mismatch."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fma_mix_exact")
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-o", exe,
+                    os.path.join(root, "tools", "micro", "fma_mix_exact.hip")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout + r.stderr
+
+
 def test_device_math_equals_the_oracles_on_every_input_the_path_can_produce(tmp_path, orc):
     """trt-math v2 on the device (rt_device.h) against the CPU checker's statement of it, EXHAUSTIVELY over the path's input domain:
     random::<f32>() has 2^23 values, and vec3extend.rs:15-30 turns one each into theta = 2 pi u, phi = acos(1 - 2u), r = cbrt(u) -

@@ -607,12 +607,13 @@ TRT_DEV void compact_leaf_test(const SceneAcc<MODE>& sc, const float4* __restric
 
 // The box-step loop of walk_compact by hand, like box_loop_lds (same reasons, same conventions): one 16-byte node per trip through the
 // scalar-base form of global_load (a 32-bit byte offset in ONE register instead of a 64-bit address in two).  Round 3: 37 vector + 10 scalar
-// instructions per trip instead of the compiler's 38 + 21; round 5: 28 vector.
+// instructions per trip instead of the compiler's 38 + 21; round 5: 22 vector.
 // FUSED SLAB ARITHMETIC (round 5).  After the NaN-ray fix this walk is bound by VALU issue (3.25 cycles per wave-instruction per SIMD against ~2.7
 // for its mix at full issue), and a third of a trip was the reference's `(x - o) * inv` on six planes: six subtractions, six multiplications.  The
 // COARSE walk need not be the reference's arithmetic - only conservative: a leaf whose coarse box passes is re-tested on its exact f32 box with
 // the reference's own slab test before its primitive is touched (walk_compact below), so a coarse test may accept too much, never too little.
-// Here a plane's distance is g = fma(x, inv, -m), m = fl(o * inv) (one v_mul per axis and call): six instructions per trip instead of twelve.
+// Here a plane's distance is g = fma(x, inv, -m), m = fl(o * inv) (one v_mul per axis and call), and the f16 -> f32 conversion of x rides in the same
+// instruction (v_fma_mix_f32): six instructions per trip instead of the eighteen of rounds 3-4 (six conversions, six subtractions, six multiplications).
 // Error against the real number F(x) = (x - o) inv (inv the f32 value both sides use): |g - F(x)| <= u |inv| (|x| + 2.001 |o|), u = 2^-24; the
 // reference's f(x) = fl(fl(x - o) inv) on the EXACT plane x0 errs by at most 2.001 u |inv| (|x0| + |o|).  The node boxes were grown by
 // eps = 2^-19 B per axis before their outward rounding to f16 (scene_host.cpp; B = largest |coordinate| on the axis): for |o| <= 4 B that is
@@ -628,9 +629,9 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
     uint32_t cnt;
     asm volatile(
         "s_mov_b64 %[sv], exec\n"
-        "v_mul_f32_e32 v57, %[ox], %[ix]\n"                  // m = fl(o * 1/d) per axis, once per call: a plane's distance is fma(x, 1/d, -m)
-        "v_mul_f32_e32 v58, %[oy], %[iy]\n"
-        "v_mul_f32_e32 v59, %[oz], %[iz]\n"
+        "v_mul_f32_e64 v57, -%[ox], %[ix]\n"                 // -m = fl(-o * 1/d) per axis, once per call: a plane's distance is fma(x, 1/d, -m)
+        "v_mul_f32_e64 v58, -%[oy], %[iy]\n"
+        "v_mul_f32_e64 v59, -%[oz], %[iz]\n"
         "1:\n"
         "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < n
         "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // top != limit
@@ -640,26 +641,23 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
         "v_lshlrev_b32_e32 v52, 4, %[i]\n"
         "global_load_dwordx4 v[48:51], v52, %[nodes]\n"      // (lo.x lo.y) (lo.z hi.x) (hi.y hi.z) as f16 pairs, link
         "s_waitcnt vmcnt(0)\n"
-        "v_cvt_f32_f16_e32 v52, v48\n"                                                                    // lo.x
-        "v_cvt_f32_f16_sdwa v48, v48 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // lo.y
-        "v_cvt_f32_f16_e32 v53, v49\n"                                                                    // lo.z
-        "v_cvt_f32_f16_sdwa v49, v49 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // hi.x
-        "v_cvt_f32_f16_e32 v54, v50\n"                                                                    // hi.y
-        "v_cvt_f32_f16_sdwa v50, v50 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"               // hi.z
-        "v_fma_f32 v52, v52, %[ix], -v57\n"                  // fused: ONE rounding of x / d - m instead of the reference's two of (x - o) / d;
-        "v_fma_f32 v49, v49, %[ix], -v57\n"                  //        conservative on these boxes (they were grown for it: see above the function)
-        "v_fma_f32 v48, v48, %[iy], -v58\n"
-        "v_fma_f32 v54, v54, %[iy], -v58\n"
-        "v_fma_f32 v53, v53, %[iz], -v59\n"
-        "v_fma_f32 v50, v50, %[iz], -v59\n"
+        // one instruction per plane: v_fma_mix_f32 reads the f16 coordinate straight out of the low / high half of the node's word, converts it
+        // exactly and fuses x / d - m with ONE rounding (the reference: two, of (x - o) / d; conservative on these boxes - they were grown for it:
+        // see above the function).  Bit-identical to v_cvt_f32_f16 + v_fma_f32 for every f16 pattern: tools/micro/fma_mix_exact.hip.
+        "v_fma_mix_f32 v52, v48, %[ix], v57 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n"      // lo.x
+        "v_fma_mix_f32 v53, v48, %[iy], v58 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"      // lo.y
+        "v_fma_mix_f32 v54, v49, %[iz], v59 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n"      // lo.z
+        "v_fma_mix_f32 v49, v49, %[ix], v57 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"      // hi.x
+        "v_fma_mix_f32 v48, v50, %[iy], v58 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n"      // hi.y
+        "v_fma_mix_f32 v50, v50, %[iz], v59 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"      // hi.z
         "v_med3_f32 v55, v52, v49, %[tmin]\n"                // max(t_min, entry x)   (TRT_SLAB_MED3)
         "v_med3_f32 v52, v52, v49, %[tb]\n"                  // min(t_best, exit x)
-        "v_min_f32_e32 v56, v48, v54\n"
-        "v_max_f32_e32 v48, v48, v54\n"
-        "v_min_f32_e32 v49, v53, v50\n"
-        "v_max_f32_e32 v53, v53, v50\n"
+        "v_min_f32_e32 v56, v53, v48\n"
+        "v_max_f32_e32 v48, v53, v48\n"
+        "v_min_f32_e32 v49, v54, v50\n"
+        "v_max_f32_e32 v54, v54, v50\n"
         "v_max3_f32 v55, v55, v56, v49\n"                    // start
-        "v_min3_f32 v52, v52, v48, v53\n"                    // end
+        "v_min3_f32 v52, v52, v48, v54\n"                    // end
         "v_cmp_nle_f32_e32 vcc, v52, v55\n"                  // pass = !(end <= start)
         "v_cmp_gt_i32_e64 %[m0], 0, v51\n"                   // leaf: kCompactLeafBit is the sign bit of the fourth word
         "s_or_b64 %[m1], vcc, %[m0]\n"
