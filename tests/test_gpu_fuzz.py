@@ -158,6 +158,7 @@ def test_fma_mix_is_convert_then_fma_for_every_f16(tmp_path):
     per plane instead of a conversion and an FMA.  tools/micro/fma_mix_exact.hip compares the two forms for EVERY f16 bit pattern (subnormals
     included - flushing them would move the planes of a millimetre-sized scene by more than their boxes' slack) in both halves of a word against
     4096 (1/d, -m) pairs each: 5.4e8 fused operations, exits non-zero on any mismatch."""
+    import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = str(tmp_path / "fma_mix_exact")
