@@ -171,7 +171,8 @@ typedef struct {
     uint32_t ray_pool;                /* 1 (default): per-wave LDS pool of primary rays where it fits; 0: one ray in stock per lane   TRT_RAY_POOL */
     uint32_t stragglers;              /* 16-byte-node walk: lanes that may carry an unfinished walk into the next round (8; 0 = none)   TRT_STRAGGLERS */
     uint32_t lds_stragglers;          /* the same for the LDS tree walk (8)                                 TRT_LDS_STRAGGLERS */
-    uint32_t dual_walk;               /* scenes in global memory: two paths per lane, two node loads in flight per wave   TRT_DUAL_WALK */
+    uint32_t dual_walk;               /* scenes in global memory: two paths per lane, two node loads in flight per wave: 0 = by scene (on where the
+                                         scene's hot part exceeds the 32 MiB of L2), 1 = wherever the kernel exists, 2 = never   TRT_DUAL_WALK */
     uint32_t runtime_walk;            /* 1: the kernels that choose the walk at run time instead of the specialised ones (0)   TRT_RUNTIME_WALK */
     uint32_t xcd_remap;               /* 1: contiguous image regions per XCD (0: measured 2x slower)        TRT_XCD_REMAP */
     uint32_t mega_waves_per_simd;     /* megakernel backend: 0 = default (7)                                TRT_MINW */

@@ -49,7 +49,7 @@ inline trt_tuning tuning_builtin() {
     t.ray_pool = 1;
     t.stragglers = 8;                 // profiles/r03_stragglers_sweep.txt
     t.lds_stragglers = 8;
-    t.dual_walk = 0;                  // two paths per lane: +2 % at 6 waves per SIMD, -7 % at 8 (profiles/r04_dual_walk_sweep.txt): not the default
+    t.dual_walk = 0;                  // by scene: two paths per lane beyond L2 (+2.7 % / +4.2 % on sphere_field 1 M / 4 M, -2.6 % on the 100 k-sphere scene: profiles/r05_dual_walk_fused_ab.txt)
     t.runtime_walk = 0;
     t.xcd_remap = 0;
     t.mega_waves_per_simd = 0; t.mega_threads = 0; t.mega_global_waves8 = 0;

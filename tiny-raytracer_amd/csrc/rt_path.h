@@ -749,20 +749,17 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
 // requests are always issued and vmcnt(1) / vmcnt(0) mean "A's node" / "B's node" whatever the masks; a half whose mask is empty
 // skips its arithmetic (s_cbranch_execz).
 #define TRT_COMPACT_STEP(D0, D1, D2, D3, I, TOP)                                                                                              \
-        "v_cvt_f32_f16_e32 v52, " D0 "\n"                                                                 /* lo.x */                        \
-        "v_cvt_f32_f16_sdwa " D0 ", " D0 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* lo.y */                        \
-        "v_cvt_f32_f16_e32 v53, " D1 "\n"                                                                 /* lo.z */                        \
-        "v_cvt_f32_f16_sdwa " D1 ", " D1 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* hi.x */                        \
-        "v_cvt_f32_f16_e32 v54, " D2 "\n"                                                                 /* hi.y */                        \
-        "v_cvt_f32_f16_sdwa " D2 ", " D2 " dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n"         /* hi.z */                        \
-        "v_sub_f32_e32 v52, v52, %[ox" I "]\n v_sub_f32_e32 " D1 ", " D1 ", %[ox" I "]\n v_sub_f32_e32 " D0 ", " D0 ", %[oy" I "]\n"        \
-        "v_sub_f32_e32 v54, v54, %[oy" I "]\n v_sub_f32_e32 v53, v53, %[oz" I "]\n v_sub_f32_e32 " D2 ", " D2 ", %[oz" I "]\n"              \
-        "v_mul_f32_e32 v52, v52, %[ix" I "]\n v_mul_f32_e32 " D1 ", " D1 ", %[ix" I "]\n v_mul_f32_e32 " D0 ", " D0 ", %[iy" I "]\n"        \
-        "v_mul_f32_e32 v54, v54, %[iy" I "]\n v_mul_f32_e32 v53, v53, %[iz" I "]\n v_mul_f32_e32 " D2 ", " D2 ", %[iz" I "]\n"              \
-        "v_med3_f32 v55, v52, " D1 ", %[tmin]\n v_med3_f32 v52, v52, " D1 ", %[tb" I "]\n v_min_f32_e32 v56, " D0 ", v54\n"                \
-        "v_max_f32_e32 " D0 ", " D0 ", v54\n v_min_f32_e32 " D1 ", v53, " D2 "\n v_max_f32_e32 v53, v53, " D2 "\n"                         \
+        /* the fused, mixed-precision slab arithmetic of box_loop_compact (round 5): x / d - m in one v_fma_mix_f32 per plane */                  \
+        "v_fma_mix_f32 v52, " D0 ", %[ix" I "], %[nx" I "] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n"          /* lo.x */                              \
+        "v_fma_mix_f32 v53, " D0 ", %[iy" I "], %[ny" I "] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"          /* lo.y */                              \
+        "v_fma_mix_f32 v54, " D1 ", %[iz" I "], %[nz" I "] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n"          /* lo.z */                              \
+        "v_fma_mix_f32 " D1 ", " D1 ", %[ix" I "], %[nx" I "] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"       /* hi.x */                              \
+        "v_fma_mix_f32 " D0 ", " D2 ", %[iy" I "], %[ny" I "] op_sel:[0,0,0] op_sel_hi:[1,0,0]\n"       /* hi.y */                              \
+        "v_fma_mix_f32 " D2 ", " D2 ", %[iz" I "], %[nz" I "] op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"       /* hi.z */                              \
+        "v_med3_f32 v55, v52, " D1 ", %[tmin]\n v_med3_f32 v52, v52, " D1 ", %[tb" I "]\n v_min_f32_e32 v56, v53, " D0 "\n"                    \
+        "v_max_f32_e32 " D0 ", v53, " D0 "\n v_min_f32_e32 " D1 ", v54, " D2 "\n v_max_f32_e32 v54, v54, " D2 "\n"                             \
         "v_max3_f32 v55, v55, v56, " D1 "\n"                                                                          /* start */           \
-        "v_min3_f32 v52, v52, " D0 ", v53\n"                                                                          /* end */             \
+        "v_min3_f32 v52, v52, " D0 ", v54\n"                                                                          /* end */             \
         "v_cmp_nle_f32_e32 vcc, v52, v55\n"                                                         /* pass = !(end <= start) */            \
         "v_cmp_gt_i32_e64 %[m0], 0, " D3 "\n"                                                       /* leaf: sign bit of the link */        \
         "s_or_b64 %[m1], vcc, %[m0]\n"                                                                                                     \
@@ -770,11 +767,10 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
         "v_cndmask_b32_e64 %[i" I "], " D3 ", v56, %[m1]\n"                                         /* next node, or the skip link */       \
         "s_and_b64 %[m1], vcc, %[m0]\n"                                                             /* a leaf whose coarse box passes: */   \
         "s_and_b64 exec, exec, %[m1]\n"                                                                                                    \
-        "v_and_b32_e32 v54, 0x7fffffff, " D3 "\n"                                                                                          \
-        "ds_write2_b32 %[top" I "], v54, v55 offset1:1\n"                                           /*   (leaf number, coarse start) */     \
+        "ds_write2_b32 %[top" I "], " D3 ", v55 offset1:1\n"                                        /*   (LEAF | leaf number, coarse start) */ \
         "v_add_u32_e32 %[top" I "], 0x200, %[top" I "]\n"
 
-TRT_DEV void box_loop_compact2(uint32_t& iA, uint32_t& iB, const V3& oA, const V3& oB, const V3& invA, const V3& invB, float tbA, float tbB,
+TRT_DEV void box_loop_compact2(uint32_t& iA, uint32_t& iB, const V3& nmA, const V3& nmB, const V3& invA, const V3& invB, float tbA, float tbB,
                                const uint4* __restrict__ nodes16, float2* stkA, float2* stkB, uint32_t slots, float2*& topA_out, float2*& topB_out,
                                uint32_t n, uint32_t few) {
     const uint32_t stkA_off = lds_offset(stkA), stkB_off = lds_offset(stkB);
@@ -817,8 +813,8 @@ TRT_DEV void box_loop_compact2(uint32_t& iA, uint32_t& iB, const V3& oA, const V
         "2:\n"
         : [iA] "+v"(iA), [iB] "+v"(iB), [topA] "+v"(topA), [topB] "+v"(topB), [sv] "=&s"(saved), [mA] "=&s"(mA), [mB] "=&s"(mB), [m0] "=&s"(m0),
           [m1] "=&s"(m1), [cnt] "=&s"(cnt), [cnt2] "=&s"(cnt2)
-        : [n] "s"(n), [few] "s"(few), [nodes] "s"(nodes16), [limA] "v"(limA), [limB] "v"(limB), [oxA] "v"(oA.x), [oyA] "v"(oA.y), [ozA] "v"(oA.z),
-          [ixA] "v"(invA.x), [iyA] "v"(invA.y), [izA] "v"(invA.z), [tbA] "v"(tbA), [oxB] "v"(oB.x), [oyB] "v"(oB.y), [ozB] "v"(oB.z), [ixB] "v"(invB.x),
+        : [n] "s"(n), [few] "s"(few), [nodes] "s"(nodes16), [limA] "v"(limA), [limB] "v"(limB), [nxA] "v"(nmA.x), [nyA] "v"(nmA.y), [nzA] "v"(nmA.z),
+          [ixA] "v"(invA.x), [iyA] "v"(invA.y), [izA] "v"(invA.z), [tbA] "v"(tbA), [nxB] "v"(nmB.x), [nyB] "v"(nmB.y), [nzB] "v"(nmB.z), [ixB] "v"(invB.x),
           [iyB] "v"(invB.y), [izB] "v"(invB.z), [tbB] "v"(tbB), [tmin] "s"(kTMin)
         : "vcc", "scc", "memory", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56");
     topA_out = stkA + ((topA - stkA_off) >> 3);
@@ -839,7 +835,9 @@ TRT_DEV void walk_compact2(const SceneAcc<MODE>& sc, const uint4* __restrict__ n
     const uint32_t few = stragglers < entered ? stragglers : entered - 1u;             // see walk_fast_lds
     for (;;) {
         float2 *topA, *topB;
-        box_loop_compact2(iA, iB, rayA.o, rayB.o, trA.inv, trB.inv, trA.t_best, trB.t_best, nodes16, stkA, stkB, slots, topA, topB, n, few);
+        // -m = fl(-o * 1/d) per axis (box_loop_compact): recomputed per call from the rays, so that nothing but the rays stays live across the shades
+        const V3 nmA = v3(-rayA.o.x * trA.inv.x, -rayA.o.y * trA.inv.y, -rayA.o.z * trA.inv.z), nmB = v3(-rayB.o.x * trB.inv.x, -rayB.o.y * trB.inv.y, -rayB.o.z * trB.inv.z);
+        box_loop_compact2(iA, iB, nmA, nmB, trA.inv, trB.inv, trA.t_best, trB.t_best, nodes16, stkA, stkB, slots, topA, topB, n, few);
         TRT_CLK(ctr, 1);
         if (topA != stkA) leaf_phase<MODE, false>(stkA, topA, trA, ctr, [&](uint32_t leaf) { compact_leaf_test<MODE, false>(sc, leaf_list, rayA, trA, leaf, ctr); });
         if (topB != stkB) leaf_phase<MODE, false>(stkB, topB, trB, ctr, [&](uint32_t leaf) { compact_leaf_test<MODE, false>(sc, leaf_list, rayB, trB, leaf, ctr); });

@@ -404,7 +404,7 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_dual_kernel(SceneDev scd
         take(B);
         if (__builtin_amdgcn_ballot_w64(A.has_path || B.has_path) == 0ull) break;          // the batches are used up
         TRT_CLK(ctr, 0);
-        Trav trA = trav_begin(sc, A.p.ray, false), trB = trav_begin(sc, B.p.ray, false);   // a new walk, or the frame of a parked one
+        Trav trA = trav_begin<MODE, true>(sc, A.p.ray, false), trB = trav_begin<MODE, true>(sc, B.p.ray, false);   // a new walk, or the frame of a parked one (fused-slab domain: rt_path.h)
         if (A.has_path) { if (A.walking) trav_unpark(stkA, trA); else n_rays++; }
         if (B.has_path) { if (B.walking) trav_unpark(stkB, trB); else n_rays++; }
         const uint32_t entered = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(A.has_path)) +
@@ -561,9 +561,16 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     // (round 5, without the NaN-ray tail and with the fused slab arithmetic: a tree that fits the chip's 32 MiB of L2 runs 5 % faster at 7 waves
     // with no spilled register than at 8 with ten; a scene whose walk waits for memory - sphere_field, 1 M spheres and up - wants the eighth wave:
     // profiles/r05_waves7_ab.txt)
-    int w = mode == MODE_LDS ? 6 : (L.hot_bytes <= (32u << 20) ? 7 : 8);
+    // Two paths per lane (stream_dual_kernel; trt_tuning.dual_walk: 0 by scene, 1 wherever the kernel exists, 2 never): with the fused box step in its loop
+    // it LOSES 2.6 % where the tree fits L2 and WINS 2.7 % / 4.2 % on sphere_field 1 M / 4 M at 6 waves - where the walk's loads really miss, a second
+    // node load in flight per lane pays (profiles/r05_dual_walk_fused_ab.txt): by scene = beyond L2, when nothing else about the launch was asked for.
+    const bool beyond_l2 = mode == MODE_GLOBAL && L.hot_bytes > (32u << 20);
+    const bool want_dual = mode == MODE_GLOBAL && (tn.dual_walk == 1u || (tn.dual_walk == 0u && beyond_l2 && tn.stream_waves_per_simd == 0u && !stats && !ra_all.ref_tree &&
+                                                                           L.lazy_color && tn.runtime_walk == 0u && tn.ray_pool != 0u && ra_all.lds_leaf_stack != 0u &&
+                                                                           L.off_compact != 0u));
+    int w = mode == MODE_LDS ? 6 : (beyond_l2 ? (want_dual ? 6 : 8) : 7);
     if (tn.stream_waves_per_simd) w = (int)tn.stream_waves_per_simd;
-    if (w < 5 && !(tn.dual_walk != 0u && mode == MODE_GLOBAL && w == 4)) w = 5;      // (4: the two-path kernel only - eight rays per SIMD like 8 x 1)
+    if (w < 5 && !(want_dual && w == 4)) w = 5;      // (4: the two-path kernel only - eight rays per SIMD like 8 x 1)
     if (w > 8) w = 8;
     if (threads == 512 && w > 6) w = 6;
     if (threads == 768) w = 6;
@@ -600,7 +607,7 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     // per-wave pool of primary rays (stream_pool_kernel): needs the LDS stack and 256-lane workgroups (LDS scenes at 6
     // waves per SIMD and more, global-memory scenes at 8), and must not cost a resident workgroup either
     const size_t pool_bytes = (size_t)threads / 64u * 64u * kPoolDwords * sizeof(uint32_t);
-    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && (w >= 7 || tn.dual_walk != 0u)));
+    bool pool = lds_stack && threads == 256 && !ra_all.ref_tree && ((mode == MODE_LDS && w >= 6) || (mode == MODE_GLOBAL && (w >= 7 || want_dual)));
     pool = pool && tn.ray_pool != 0u;
     if (pool) pool = (uint32_t)(kLdsPerCu / (with_stack + pool_bytes)) >= wg_per_cu;
 
@@ -610,7 +617,7 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     const bool specialise = !stats && slots_ok && L.lazy_color && tn.runtime_walk == 0u;
     // two paths per lane (stream_dual_kernel): scenes in global memory on 16-byte nodes with the ray pool; two leaf stacks per lane, as deep
     // as fit beside the pool (2..4 slots: a parked walk needs two)
-    bool dual = tn.dual_walk != 0u && specialise && compact && pool && threads == 256;
+    bool dual = want_dual && specialise && compact && pool && threads == 256;
     if (dual) {
         uint32_t ds = ra_all.leaf_slots == 0u ? 4u : (ra_all.leaf_slots < 2u ? 2u : (ra_all.leaf_slots > kLdsLeafSlotsMax ? kLdsLeafSlotsMax : ra_all.leaf_slots));
         while (ds > 2u && (align16(scene_bytes) + 2u * (size_t)threads * ds * sizeof(float2) + pool_bytes) * wg_per_cu > kLdsPerCu) ds--;
@@ -625,6 +632,7 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
     }
     if (!k) dual = false;
     if (!dual && w < 5) { w = 5; wg_per_cu = (uint32_t)(w * 4 * 64 / threads); }             // four waves per SIMD exist for the two-path kernel only
+    if (!dual && want_dual && tn.dual_walk == 0u) { w = 8; wg_per_cu = (uint32_t)(w * 4 * 64 / threads); }      // the plan's own wish fell through: the one-path shape of a scene beyond L2
     pl.specialised = k != nullptr;
     if (!k) {
         // the general instantiations exist for fewer (waves, pool) combinations than the knobs can ask for: take the nearest one
