@@ -17,7 +17,7 @@ out=gpurun_out/knobs; mkdir -p $out
 skip='not leaf_slots_are and not lockstep and not global_memory_walks and not full_size_schedules and not full_baseline and not cfg5 and not at_size and not full_sample_count and not hbm_held'
 for e in "TRT_RAY_POOL=0" "TRT_FLAT_WALK=0" "TRT_LDS_LEAF_STACK=0" "TRT_COMPACT_NODES=0" "TRT_STREAM_MINW=5" "TRT_STREAM_MINW=7" "TRT_STREAM_MINW=8" "TRT_LEAF_SLOTS=1" "TRT_LEAF_SLOTS=2" \
          "TRT_RUNTIME_WALK=1" "TRT_BIG_THREADS=512" "TRT_STRAGGLERS=0" "TRT_STRAGGLERS=40" "TRT_LDS_STRAGGLERS=0" "TRT_LDS_STRAGGLERS=24" "TRT_CULL_PRUNE=0.8" \
-         "TRT_DUAL_WALK=1" "TRT_DUAL_WALK=1 TRT_STREAM_MINW=6" "TRT_DUAL_WALK=1 TRT_STREAM_MINW=4 TRT_STRAGGLERS=0" "TRT_STREAM_BATCH_SPP=3" "TRT_RADIANCE_GB=1" $TRT_EXTRA_KNOBS; do
+         "TRT_DUAL_WALK=1" "TRT_DUAL_WALK=2" "TRT_DUAL_WALK=1 TRT_STREAM_MINW=6" "TRT_DUAL_WALK=1 TRT_STREAM_MINW=4 TRT_STRAGGLERS=0" "TRT_STREAM_BATCH_SPP=3" "TRT_RADIANCE_GB=1" $TRT_EXTRA_KNOBS; do
   log=$out/$(echo "$e" | tr "/ " "__").log
   env $e AMD_LOG_LEVEL=1 PYTHONFAULTHANDLER=1 timeout -k 10 300 python3 -X faulthandler -m pytest tests -x -q -m gpu -k "$skip" > "$log" 2>&1
   rc=$?
