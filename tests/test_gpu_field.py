@@ -24,6 +24,9 @@ def field(trt):
 
 
 def test_field_plan_takes_two_paths_per_lane_beyond_l2(trt, field):
+    import os
+    if any(k.startswith("TRT_") and k not in ("TRT_LIB_PATH", "TRT_BENCH_REHEARSAL") for k in os.environ):
+        pytest.skip("TRT_* variables are set: the library's default tuning was overridden at load (tools/test_knobs.sh)")
     pw, pcam = trt.world_from_description(field)
     info = pw.get_bvh().info()
     assert info["num_spheres"] == N + 1 and info["num_nodes"] == 2 * N + 1 and info["lds_bytes"] == 0 and info["device_bytes"] > 150e6
