@@ -47,8 +47,23 @@ def step_range(i, spp_per_step, frame_spp=FRAME_SPP):
     return k * spp_per_step, (k + 1) * spp_per_step, (0 if k == 0 else 1)
 
 
+_COMMENT_OR_STRING = None
+
+
+def strip_comments(text):
+    """C / C++ source without its comments and with runs of blanks collapsed (string literals - the hand-written asm blocks - kept as they are):
+    what the compiler sees.  A comment-only edit must not turn a stored PMC profile stale."""
+    import re
+    global _COMMENT_OR_STRING
+    if _COMMENT_OR_STRING is None:
+        _COMMENT_OR_STRING = re.compile(r'''("(?:\\.|[^"\\\n])*"|'(?:\\.|[^'\\\n])*')|//[^\n]*|/\*.*?\*/''', re.S)
+    code = _COMMENT_OR_STRING.sub(lambda m: m.group(1) or " ", text)
+    return "\n".join(" ".join(line.split()) for line in code.splitlines() if line.strip())
+
+
 def kernel_source_digest():
-    """sha256 over the kernel sources: a PMC profile is only valid for the build it was taken from."""
+    """sha256 over the kernel sources AS THE COMPILER SEES THEM (comments stripped, blanks collapsed): a PMC profile is only valid for the build it was
+    taken from.  (Until round 5 the raw bytes were hashed, so rewording a comment cost a re-profile.)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "tiny-raytracer_amd", "csrc")
@@ -56,8 +71,9 @@ def kernel_source_digest():
         if name == "capi.hip":
             continue                  # host-side C ABI only: no device code, nothing a kernel's counters depend on
         if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+            with open(os.path.join(d, name), "r", encoding="utf-8", errors="replace") as f:
+                text = f.read()
+            h.update(name.encode() + b"\0" + (text if name == "Makefile" else strip_comments(text)).encode("utf-8"))
     return h.hexdigest()[:16]
 
 

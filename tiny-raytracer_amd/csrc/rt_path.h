@@ -732,17 +732,18 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Two walks per lane (round 4; opt-in: trt_tuning.dual_walk).  walk_compact keeps ONE 16-byte load in flight per wave, and a trip waits for
-// it: at eight waves per SIMD that is eight loads in flight per SIMD, 42 % of all wave-cycles parked in s_waitcnt
-// (profiles/r03_grid100k_pmc.json) and the vector unit issuing 0.42 of its slots.  Eight is the most waves a SIMD holds, so more loads
-// in flight have to come from inside a wave: every lane walks TWO rays, A and B, each exactly as walk_compact walks one (same node
-// order, same tests, same t_best evolution - the two walks share nothing but the instruction stream), and a trip requests both rays'
-// nodes before it waits for the first.
-// MEASURED (profiles/r04_dual_walk_sweep.txt): at equal rays in flight (2 x 4 waves against 1 x 8) the two forms run alike; 10 and 12
-// rays per SIMD give +0..+2 %, 14 and 16 lose to spills; s_waitcnt's share of the wave-cycles falls from 0.42 to 0.34 and the launch
-// gets 2 % shorter.  The walk was never waiting for ITS load: it queues for the texture addresser / L1 and for vector issue, which all
-// rays in flight share - the 100 k-sphere scene saturates at ~3.0 Gray/s from 10 rays per SIMD up.  Hence opt-in, not the default.  box_loop_compact2 is box_loop_compact's body twice between the two requests and the two waits; the registers it works in
-// (v44-v57) are shared by the two halves, the loads land in v[44:47] and v[48:51].
+// Two walks per lane (round 4; trt_tuning.dual_walk).  walk_compact keeps ONE 16-byte load in flight per wave, and a trip waits for it.  Eight is
+// the most waves a SIMD holds, so more loads in flight have to come from inside a wave: every lane walks TWO rays, A and B, each exactly as
+// walk_compact walks one (same node order, same tests, same t_best evolution - the two walks share nothing but the instruction stream), and a trip
+// requests both rays' nodes before it waits for the first.
+// MEASURED.  Round 4 (profiles/r04_dual_walk_sweep.txt) found +0..+2 % on the 100 k-sphere scene and concluded that the walk "saturates at 3.0
+// Gray/s"; those launches carried NaN rays walking the whole tree (ray_has_nan above).  Round 5, without them and with box_loop_compact's fused,
+// mixed-precision box step in this loop too (profiles/r05_dual_walk_fused_ab.txt): where the tree fits L2 one path per lane at 7 waves beats two
+// paths at 4 / 5 / 6 / 7 waves (5.49 against 4.82 / 5.21 / 5.34 / 5.17 Gray/s), where the walk's loads really miss - sphere_field, 1 M / 4 M spheres,
+// L2 hit rate 0.948 - two paths at 6 waves win 2.7 % / 4.2 %.  The launch plan therefore takes this kernel by scene size (dual_walk = 0: beyond the
+// 32 MiB of L2; 1: wherever it exists; 2: never).
+// box_loop_compact2 is box_loop_compact's body twice between the two requests and the two waits; the registers it works in (v44-v56) are shared by
+// the two halves, the loads land in v[44:47] and v[48:51].
 // A walk that is not active (no ray in that slot, or its walk is over) comes in with i == n; a slot's lanes are masked by an SGPR
 // pair recomputed every trip (i < n && top != limit), and the loop ends when at most `few` RAYS of the wave (both slots counted) can
 // still step - 0 when the last one is done.  A VMEM instruction issued with exec == 0 moves no data but keeps vmcnt in step, so both

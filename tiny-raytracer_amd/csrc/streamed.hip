@@ -291,9 +291,9 @@ __global__ __launch_bounds__(THREADS, MINW) void stream_pool_kernel(SceneDev scd
 // The pool kernel for scenes in global memory with TWO paths per lane (rt_path.h walk_compact2): slot A and slot B of a lane are two
 // independent paths - each takes its primary rays from the wave's pool, walks, is shaded and stores its radiance exactly as the one
 // path of stream_pool_kernel does - and a round steps both walks in one loop that keeps two node loads in flight per wave.  LDS per
-// wave: two postponed-leaf stacks (slot A's, then slot B's) and the ray pool.  Opt-in (trt_tuning.dual_walk): measured +2 % at 6 waves per
-// SIMD and -7 % at 8 against the one-path kernel at 8 (rt_path.h box_loop_compact2 has the finding).  Which lane and which slot traces which sample
-// changes; no sample's radiance does (RNG keyed by pixel and sample, radiance stored per sample, folded in order).
+// wave: two postponed-leaf stacks (slot A's, then slot B's) and the ray pool.  The launch plan takes it for scenes beyond L2 (trt_tuning.dual_walk = 0: by
+// scene): -2.6 % where the tree fits L2, +2.7 % / +4.2 % on sphere_field 1 M / 4 M (rt_path.h box_loop_compact2 has the finding).  Which lane and which slot
+// traces which sample changes; no sample's radiance does (RNG keyed by pixel and sample, radiance stored per sample, folded in order).
 // ------------------------------------------------------------------------------------------------------------------
 struct DualSlot {
     Path p;
@@ -555,9 +555,8 @@ StreamLaunchPlan streamed_launch_plan(const SceneLayout& L, const RenderArgs& ra
         threads = (align16(scene_bytes) + 768u * 4u * sizeof(float2)) * 2u <= kLdsPerCu && ra_all.lds_leaf_stack != 0u ? 768 : 512;
         if (tn.stream_big_threads == 512u || tn.stream_big_threads == 768u) threads = (int)tn.stream_big_threads;
     }
-    // LDS scenes: 6 waves per SIMD.  Scenes in global memory are bound by the latency of one dependent 16-byte load per box
-    // step once the compact nodes halved their load count: 8 waves per SIMD (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6,
-    // 2.29 at 8)
+    // LDS scenes: 6 waves per SIMD.  Scenes in global memory: rounds 1-4 ran them at 8 (100 k spheres: 2.03 Gray/s at 5 waves, 2.25 at 6, 2.29 at 8 -
+    // measured with NaN rays walking the whole tree in every launch: rt_path.h ray_has_nan)
     // (round 5, without the NaN-ray tail and with the fused slab arithmetic: a tree that fits the chip's 32 MiB of L2 runs 5 % faster at 7 waves
     // with no spilled register than at 8 with ten; a scene whose walk waits for memory - sphere_field, 1 M spheres and up - wants the eighth wave:
     // profiles/r05_waves7_ab.txt)

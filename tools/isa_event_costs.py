@@ -25,14 +25,12 @@ FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-v
 
 
 def kernel_source_digest():
-    h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)):
-        if name == "capi.hip":
-            continue
-        if name.endswith((".hip", ".h", ".cpp")) or name == "Makefile":
-            with open(os.path.join(CSRC, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
+    """bench.py's digest of the kernel sources (comments stripped): one function, imported, so that the two can never disagree."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module_for_digest", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b.kernel_source_digest()
 
 
 def count_kernels(asm_text):
