@@ -154,6 +154,10 @@ def test_fused_slab_walk_in_and_out_of_its_domain(trt, orc, case):
     gpu = r.render(pcam, pw).data
     assert_bit_equal(gpu, cpu, case)
     assert r.last_stats["rays"] == cst["rays"]
+    for tuning in ({"runtime_walk": 1}, {"dual_walk": 1}):            # the general kernels and the two-paths-per-lane kernel run the same loop: same domain
+        r2 = trt.Renderer(3, 1, 50, False, d2["background"], seed=11)
+        r2.tuning = tuning
+        assert_bit_equal(r2.render(pcam, pw).data, cpu, f"{case} {tuning}")
     if case != "tiny scene coordinates":
         assert gpu.mean() > 0.05                                       # (the frame shows something)
 

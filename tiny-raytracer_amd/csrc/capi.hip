@@ -771,6 +771,8 @@ int trt_scene_get_compact_nodes(const trt_scene* s, uint32_t* words4, uint32_t c
     if (L.off_compact == 0u) return fail(TRT_ERR_NOT_FOUND, "scene has no compact node array (it is walked from LDS)");
     if (cap < L.n_cull_nodes) return fail(TRT_ERR_INVALID_ARG, "buffer too small");
     memcpy(words4, s->host.blob.data() + 16u * (size_t)L.off_compact, 16u * (size_t)L.n_cull_nodes);
+    for (uint32_t i = 0; i < L.n_cull_nodes; i++)                       // stored as byte offsets (the walk's cursor); reported as node indices
+        if (!(words4[4u * (size_t)i + 3u] & 0x80000000u)) words4[4u * (size_t)i + 3u] >>= 4;
     return TRT_OK;
 }
 

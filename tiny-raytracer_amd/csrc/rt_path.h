@@ -117,15 +117,16 @@ struct Trav {
 // ref_tree: walk the reference tree whatever the ray (counting kernels: their counters then equal the oracle's).
 // A ray whose slab arithmetic can produce NaN (zero / non-finite direction component, non-finite origin) always
 // walks the reference tree with the reference's compare-and-assign slab test.
-// COMPACT_DOMAIN (kernels whose walk is walk_compact with the hand-written loop): the fast path also needs the ray inside the domain in which that
-// loop's fused slab arithmetic is conservative - |o| <= SceneLayout::compact_origin_limit per axis and |1/d| <= 2^60 (box_loop_compact).
+// COMPACT_DOMAIN / compact_domain (every walk that can reach walk_compact's hand-written loop - known at compile time in the specialised kernels,
+// at run time in the general ones): the fast path also needs the ray inside the domain in which that loop's fused slab arithmetic is
+// conservative - |o| <= SceneLayout::compact_origin_limit per axis and |1/d| <= 2^60 (box_loop_compact).
 template <int MODE, bool COMPACT_DOMAIN = false>
-TRT_DEV Trav trav_begin(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree) {
+TRT_DEV Trav trav_begin(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, bool compact_domain = false) {
     Trav tr;
     tr.inv = v3(1.0f / ray.d.x, 1.0f / ray.d.y, 1.0f / ray.d.z);     // (the short division of rt_device.h gains nothing here: measured)
     tr.fast = sc.L.all_finite && finite_f(tr.inv.x) && finite_f(tr.inv.y) && finite_f(tr.inv.z) && finite_f(ray.o.x) &&
               finite_f(ray.o.y) && finite_f(ray.o.z);
-    if constexpr (COMPACT_DOMAIN) {
+    if (COMPACT_DOMAIN || compact_domain) {
         const float big = 1152921504606846976.0f;                    // 2^60
         tr.fast = tr.fast && __builtin_fabsf(ray.o.x) <= sc.L.compact_origin_limit[0] && __builtin_fabsf(ray.o.y) <= sc.L.compact_origin_limit[1] &&
                   __builtin_fabsf(ray.o.z) <= sc.L.compact_origin_limit[2] && __builtin_fabsf(tr.inv.x) <= big && __builtin_fabsf(tr.inv.y) <= big &&
@@ -362,7 +363,7 @@ TRT_DEV float2* box_loop_lds(Trav& tr, const V3& o, float2* stk, float2* limit, 
     asm volatile(
         "s_mov_b64 %[sv], exec\n"
         "1:\n"
-        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < n
+        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < end (both in bytes)
         "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // top != limit
         "s_and_b64 vcc, vcc, %[m0]\n"
         "s_and_b64 exec, exec, vcc\n"                        // lanes that fail either leave the loop for good
@@ -621,7 +622,9 @@ TRT_DEV void compact_leaf_test(const SceneAcc<MODE>& sc, const float4* __restric
 // coarse interval contains the reference's interval on the exact box, min / max / med3 are monotonic, hence "exact box passes" implies "coarse
 // box passes" and the coarse `start` is no later than the exact one (what the leaf phase's early drop relies on).  Rays outside the domain
 // (|o| > 4 B on an axis, |inv| > 2^60) are not `fast` (trav_begin COMPACT_DOMAIN) and walk the reference tree.  Overflow: |x inv| <= 1e12 * 2^60.
-TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict__ nodes16, float2* stk, float2* limit, uint32_t n, uint32_t few) {
+// The cursor tr.i of this walk is the node's BYTE offset (16 i) and the inner nodes' links are stored that way (scene_host.cpp), so that a trip
+// needs no shift before its load; `end` = 16 n.
+TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict__ nodes16, float2* stk, float2* limit, uint32_t end, uint32_t few) {
     const uint32_t stk_off = lds_offset(stk);
     uint32_t top = stk_off;
     const uint32_t lim = lds_offset(limit);
@@ -633,13 +636,12 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
         "v_mul_f32_e64 v58, -%[oy], %[iy]\n"
         "v_mul_f32_e64 v59, -%[oz], %[iz]\n"
         "1:\n"
-        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < n
+        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < end (both in bytes)
         "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // top != limit
         "s_and_b64 vcc, vcc, %[m0]\n"
         "s_and_b64 exec, exec, vcc\n"
         "s_cbranch_scc0 2f\n"
-        "v_lshlrev_b32_e32 v52, 4, %[i]\n"
-        "global_load_dwordx4 v[48:51], v52, %[nodes]\n"      // (lo.x lo.y) (lo.z hi.x) (hi.y hi.z) as f16 pairs, link
+        "global_load_dwordx4 v[48:51], %[i], %[nodes]\n"     // (lo.x lo.y) (lo.z hi.x) (hi.y hi.z) as f16 pairs, link; the cursor IS the byte offset
         "s_waitcnt vmcnt(0)\n"
         // one instruction per plane: v_fma_mix_f32 reads the f16 coordinate straight out of the low / high half of the node's word, converts it
         // exactly and fuses x / d - m with ONE rounding (the reference: two, of (x - o) / d; conservative on these boxes - they were grown for it:
@@ -661,8 +663,8 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
         "v_cmp_nle_f32_e32 vcc, v52, v55\n"                  // pass = !(end <= start)
         "v_cmp_gt_i32_e64 %[m0], 0, v51\n"                   // leaf: kCompactLeafBit is the sign bit of the fourth word
         "s_or_b64 %[m1], vcc, %[m0]\n"
-        "v_add_u32_e32 v56, 1, %[i]\n"
-        "v_cndmask_b32_e64 %[i], v51, v56, %[m1]\n"          // first child / a leaf's successor, or the skip link
+        "v_add_u32_e32 v56, 16, %[i]\n"
+        "v_cndmask_b32_e64 %[i], v51, v56, %[m1]\n"          // first child / a leaf's successor, or the skip link (a byte offset too)
         "s_and_b64 %[m1], vcc, %[m0]\n"                      // a leaf whose coarse box passes:
         "s_and_saveexec_b64 %[m0], %[m1]\n"
         "ds_write2_b32 %[top], v51, v55 offset1:1\n"         //   put (LEAF | leaf sequence number, coarse start) aside (compact_leaf_test strips the bit)
@@ -674,7 +676,7 @@ TRT_DEV float2* box_loop_compact(Trav& tr, const V3& o, const uint4* __restrict_
         "2:\n"
         "s_mov_b64 exec, %[sv]\n"
         : [i] "+v"(tr.i), [top] "+v"(top), [sv] "=&s"(saved), [m0] "=&s"(m0), [m1] "=&s"(m1), [cnt] "=&s"(cnt)
-        : [n] "s"(n), [few] "s"(few), [nodes] "s"(nodes16), [lim] "v"(lim), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(tr.inv.x),
+        : [n] "s"(end), [few] "s"(few), [nodes] "s"(nodes16), [lim] "v"(lim), [ox] "v"(o.x), [oy] "v"(o.y), [oz] "v"(o.z), [ix] "v"(tr.inv.x),
           [iy] "v"(tr.inv.y), [iz] "v"(tr.inv.z), [tb] "v"(tr.t_best), [tmin] "s"(kTMin)
         : "vcc", "scc", "memory", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59");
     return stk + ((top - stk_off) >> 3);
@@ -691,7 +693,7 @@ template <int MODE, bool STATS>
 TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list,
                           const Ray& ray, Trav& tr, Counters<STATS>& ctr, float2* stk, uint32_t slots, uint32_t stragglers = 0u,
                           uint32_t entered = 64u) {
-    const uint32_t n = sc.L.n_cull_nodes;
+    const uint32_t n = sc.L.n_cull_nodes << 4;                                         // tr.i counts bytes in this walk (box_loop_compact)
     float2* const limit = stk + 64u * slots;
     const uint32_t few = stragglers < entered ? stragglers : entered - 1u;             // see walk_fast_lds
     for (;;) {
@@ -704,14 +706,14 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
             top = box_loop_compact(tr, ray.o, nodes16, stk, limit, n, few);
         } else
         while (tr.i < n && top != limit) {
-            const uint4 q = nodes16[tr.i];
+            const uint4 q = nodes16[tr.i >> 4];
             if constexpr (STATS) { ctr.node++; if (first_active_lane()) ctr.w_steps++; }
             const half2_t a = __builtin_bit_cast(half2_t, q.x), b = __builtin_bit_cast(half2_t, q.y), c = __builtin_bit_cast(half2_t, q.z);
             float start;
             const bool pass = slab_fast6_entry(v3((float)a.x, (float)a.y, (float)b.x), v3((float)b.y, (float)c.x, (float)c.y), ray.o, tr.inv,
                                                kTMin, tr.t_best, start);
             const bool is_leaf = (q.w & kCompactLeafBit) != 0u;
-            const uint32_t next = tr.i + 1u;                                         // first child, or a leaf's successor
+            const uint32_t next = tr.i + 16u;                                        // first child, or a leaf's successor
             if (pass && is_leaf) {
                 *top = make_float2(__uint_as_float(q.w & ~kCompactLeafBit), start);
                 top += 64;
@@ -764,7 +766,7 @@ TRT_DEV bool walk_compact(const SceneAcc<MODE>& sc, const uint4* __restrict__ no
         "v_cmp_nle_f32_e32 vcc, v52, v55\n"                                                         /* pass = !(end <= start) */            \
         "v_cmp_gt_i32_e64 %[m0], 0, " D3 "\n"                                                       /* leaf: sign bit of the link */        \
         "s_or_b64 %[m1], vcc, %[m0]\n"                                                                                                     \
-        "v_add_u32_e32 v56, 1, %[i" I "]\n"                                                                                                \
+        "v_add_u32_e32 v56, 16, %[i" I "]\n"                                                                                               \
         "v_cndmask_b32_e64 %[i" I "], " D3 ", v56, %[m1]\n"                                         /* next node, or the skip link */       \
         "s_and_b64 %[m1], vcc, %[m0]\n"                                                             /* a leaf whose coarse box passes: */   \
         "s_and_b64 exec, exec, %[m1]\n"                                                                                                    \
@@ -794,11 +796,9 @@ TRT_DEV void box_loop_compact2(uint32_t& iA, uint32_t& iB, const V3& nmA, const 
         "s_cmp_le_u32 %[cnt], %[few]\n"                       // at most `few` rays can still step (0: none): leave
         "s_cbranch_scc1 2f\n"
         "s_mov_b64 exec, %[mA]\n"
-        "v_lshlrev_b32_e32 v52, 4, %[iA]\n"
-        "global_load_dwordx4 v[44:47], v52, %[nodes]\n"
+        "global_load_dwordx4 v[44:47], %[iA], %[nodes]\n"    // (cursors are byte offsets: box_loop_compact)
         "s_mov_b64 exec, %[mB]\n"
-        "v_lshlrev_b32_e32 v53, 4, %[iB]\n"
-        "global_load_dwordx4 v[48:51], v53, %[nodes]\n"
+        "global_load_dwordx4 v[48:51], %[iB], %[nodes]\n"
         "s_mov_b64 exec, %[mA]\n"
         "s_waitcnt vmcnt(1)\n"
         "s_cbranch_execz 3f\n"
@@ -828,7 +828,7 @@ template <int MODE>
 TRT_DEV void walk_compact2(const SceneAcc<MODE>& sc, const uint4* __restrict__ nodes16, const float4* __restrict__ leaf_list, const Ray& rayA,
                            Trav& trA, bool actA, const Ray& rayB, Trav& trB, bool actB, Counters<false>& ctr, float2* stkA, float2* stkB,
                            uint32_t slots, uint32_t stragglers, uint32_t entered, bool& doneA, bool& doneB) {
-    const uint32_t n = sc.L.n_cull_nodes;
+    const uint32_t n = sc.L.n_cull_nodes << 4;                                         // cursors count bytes (box_loop_compact)
     // the rare walks (a ray whose slab arithmetic can produce NaN): reference tree, to the end, one slot after the other
     if (actA && trA.ref) { closest_hit_ref<MODE, false>(sc, rayA, trA, ctr); trA.i = n; }
     if (actB && trB.ref) { closest_hit_ref<MODE, false>(sc, rayB, trB, ctr); trB.i = n; }
@@ -865,7 +865,9 @@ template <int MODE, bool STATS, int WALK = WALK_RUNTIME>
 TRT_DEV uint32_t closest_hit(const SceneAcc<MODE>& sc, const Ray& ray, bool ref_tree, float& t_hit, Counters<STATS>& ctr,
                              uint32_t leaf_slots = 4u, float2* lds_stack = nullptr, const float4* __restrict__ leaf_list = nullptr,
                              const uint4* __restrict__ nodes16 = nullptr) {
-    Trav tr = trav_begin(sc, ray, ref_tree);
+    // (a general kernel reaches walk_compact's loop whenever it is handed the 16-byte nodes and an LDS stack: same domain as the specialised ones)
+    const bool fused_loop = kAsmBoxLoop && !STATS && (WALK == WALK_COMPACT || (WALK == WALK_RUNTIME && lds_stack != nullptr && nodes16 != nullptr));
+    Trav tr = trav_begin<MODE>(sc, ray, ref_tree, fused_loop);
     if (__builtin_expect(!tr.ref, 1)) {
         if constexpr (WALK == WALK_COMPACT) {
             walk_compact<MODE, STATS>(sc, nodes16, leaf_list, ray, tr, ctr, lds_stack, leaf_slots);

@@ -438,6 +438,7 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
     L.off_compact = 0u;
     bool want_compact = L.hot_bytes > kLdsSceneMaxBytes;                      // scenes walked from global memory
     if (opt.compact_nodes >= 0) want_compact = opt.compact_nodes != 0;                        // tuning / tests; same frames either way
+    if (nc >= (1u << 27)) want_compact = false;                                               // (its links are byte offsets below 2^31)
     if (want_compact) {
         L.off_compact = L.blob_bytes / 16u;
         L.blob_bytes += 16u * nc;
@@ -539,7 +540,8 @@ bool compile_scene(const World& w, const trt_scene_options& opt, SceneHost& out,
             c[4 * i + 0] = lx | ly << 16;
             c[4 * i + 1] = lz | hx << 16;
             c[4 * i + 2] = hy | hz << 16;
-            c[4 * i + 3] = cb.node_leaf[i] >= 0 ? (0x80000000u | (uint32_t)cb.node_leaf[i]) : (uint32_t)cb.node_skip[i];
+            // an inner node's link is its skip node's BYTE offset in this array: the walk's cursor is the offset its load takes (box_loop_compact)
+            c[4 * i + 3] = cb.node_leaf[i] >= 0 ? (0x80000000u | (uint32_t)cb.node_leaf[i]) : (uint32_t)cb.node_skip[i] << 4;
         }
     }
     dump_tree(out.reference, b.node_box, b.node_prim, b.node_skip);
