@@ -132,7 +132,8 @@ int trt_scene_get_cull_nodes(const trt_scene *s, float *bbox6, int32_t *prim, in
 /* Scenes too large for LDS also carry the culling tree as 16-byte nodes, boxes rounded OUTWARD to IEEE half precision
  * (one load per box step instead of two; postponed leaves are re-tested against their exact f32 boxes).  Copies
  * num_cull_nodes x 4 words: (lo.x | lo.y << 16, lo.z | hi.x << 16, hi.y | hi.z << 16, link), link = skip index of an
- * inner node, or 0x80000000 | leaf sequence number.  Returns TRT_ERR_NOT_FOUND if the scene has no such array. */
+ * inner node (the device copy keeps it as a byte offset, index x 16), or 0x80000000 | leaf sequence number.  Returns
+ * TRT_ERR_NOT_FOUND if the scene has no such array. */
 int trt_scene_get_compact_nodes(const trt_scene *s, uint32_t *words4, uint32_t cap);
 
 /* ---- Camera (camera.rs:4-14, 17-56) ---- */
