@@ -363,7 +363,7 @@ TRT_DEV float2* box_loop_lds(Trav& tr, const V3& o, float2* stk, float2* limit, 
     asm volatile(
         "s_mov_b64 %[sv], exec\n"
         "1:\n"
-        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < end (both in bytes)
+        "v_cmp_gt_u32_e32 vcc, %[n], %[i]\n"                 // tr.i < n
         "v_cmp_ne_u32_e64 %[m0], %[top], %[lim]\n"           // top != limit
         "s_and_b64 vcc, vcc, %[m0]\n"
         "s_and_b64 exec, exec, vcc\n"                        // lanes that fail either leave the loop for good
