@@ -608,7 +608,7 @@ TRT_DEV void compact_leaf_test(const SceneAcc<MODE>& sc, const float4* __restric
 
 // The box-step loop of walk_compact by hand, like box_loop_lds (same reasons, same conventions): one 16-byte node per trip through the
 // scalar-base form of global_load (a 32-bit byte offset in ONE register instead of a 64-bit address in two).  Round 3: 37 vector + 10 scalar
-// instructions per trip instead of the compiler's 38 + 21; round 5: 22 vector.
+// instructions per trip instead of the compiler's 38 + 21; round 5: 21 vector.
 // FUSED SLAB ARITHMETIC (round 5).  After the NaN-ray fix this walk is bound by VALU issue (3.25 cycles per wave-instruction per SIMD against ~2.7
 // for its mix at full issue), and a third of a trip was the reference's `(x - o) * inv` on six planes: six subtractions, six multiplications.  The
 // COARSE walk need not be the reference's arithmetic - only conservative: a leaf whose coarse box passes is re-tested on its exact f32 box with
